@@ -1,0 +1,151 @@
+"""GPU parity of the universal tap-GEMM (usdm_gemm) against plain fp64 torch on the CPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _tol(dtype, K):
+    return (2e-2 if dtype == torch.bfloat16 else 2e-5)
+
+
+def _check(out, ref, dtype, K, what):
+    ref = ref.double()
+    err = (out.double().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert err <= _tol(dtype, K) * scale, f"{what}: max err {err} vs scale {scale}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(70, 50, 64), (300, 200, 96), (1118 * 2, 1024, 1024), (129, 257, 32 * 7)])
+def test_linear(dev, dtype, M, N, K):
+    from usdm_amd import ops
+    if dtype == torch.float32 and K % 16:
+        pytest.skip()
+    A = _rand((M, K), dtype, 1)
+    W = _rand((N, K), dtype, 2)
+    b = _rand((N,), torch.float32, 3)
+    R = _rand((M, N), torch.float32, 4)
+    out = torch.full((M, N), float("nan"), device=dev)
+    out16 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), residual=R.to(dev), ldr=N, out32=out, out16=out16)
+    ref = A.double() @ W.double().T + b.double() + R.double()
+    _check(out, ref, dtype, K, "linear f32 out")
+    _check(out16.float(), ref, torch.bfloat16, K, "linear bf16 out")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gelu_and_transpose(dev, dtype):
+    from usdm_amd import ops
+    M, N, K = 200, 96, 64
+    A, W = _rand((M, K), dtype, 1, 0.3), _rand((N, K), dtype, 2, 0.3)
+    b = _rand((N,), torch.float32, 3)
+    out = torch.zeros((N, M), device=dev)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), act=1, out32=out, ldc=M, transpose_out=True)
+    ref = torch.nn.functional.gelu(A.double() @ W.double().T + b.double()).T
+    _check(out, ref, dtype, K, "gelu+transpose")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("k,dil,stride", [(3, 1, 1), (7, 3, 1), (11, 5, 1), (3, 1, 2), (2, 1, 2)])
+def test_conv1d_taps(dev, dtype, k, dil, stride):
+    """Conv1d on channels-last activations == tap-GEMM (vocoder/models.py:33-49 shapes, XLS-R strides)."""
+    from usdm_amd import ops
+    T, Cin, Cout = 333, 64, 48
+    x = _rand((1, Cin, T), dtype, 5)
+    w = _rand((Cout, Cin, k), dtype, 6, 0.2)
+    b = _rand((Cout,), torch.float32, 7)
+    pad = (k * dil - dil) // 2 if stride == 1 else 0
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)[0].T
+    Tout = ref.shape[0]
+    A = x[0].T.contiguous().to(dev)                      # [T, Cin]
+    Wp = w.permute(0, 2, 1).contiguous().reshape(Cout, k * Cin).to(dev)  # [Cout][tap][Cin]
+    out = torch.zeros((Tout, Cout), device=dev)
+    ops.gemm(A, Wp, M=Tout, N=Cout, Kc=Cin, taps=k, rowsA=T, a_row_mul=stride, a_row_off=-pad, a_row_step=dil,
+             bias=b.to(dev), out32=out)
+    _check(out, ref, dtype, k * Cin, f"conv k{k} d{dil} s{stride}")
+
+
+def test_conv_transpose_phases(dev):
+    """ConvTranspose1d(k=2u, stride u, pad (k-u)//2) as u two-tap phase GEMMs (vocoder/models.py:157-162)."""
+    from usdm_amd import ops
+    dtype = torch.bfloat16
+    for (k, u) in [(8, 4), (4, 2)]:
+        T, Cin, Cout = 100, 64, 32
+        x = _rand((1, Cin, T), dtype, 8)
+        w = _rand((Cin, Cout, k), dtype, 9, 0.2)
+        b = _rand((Cout,), torch.float32, 10)
+        pad = (k - u) // 2
+        ref = torch.nn.functional.conv_transpose1d(x.double(), w.double(), b.double(), stride=u, padding=pad)[0].T
+        A = x[0].T.contiguous().to(dev)
+        out = torch.zeros((T * u, Cout), device=dev)
+        for p in range(u):
+            js = [j for j in range(k) if (p + pad - j) % u == 0]
+            js.sort(key=lambda j: (p + pad - j) // u)  # ascending input offset
+            offs = [(p + pad - j) // u for j in js]
+            assert len(js) == 2 and offs[1] - offs[0] == 1
+            Wp = torch.stack([w[:, :, j].T for j in js], dim=1).contiguous().reshape(Cout, 2 * Cin).to(dev)
+            ops.gemm(A, Wp, M=T, N=Cout, Kc=Cin, taps=2, rowsA=T, a_row_off=offs[0], a_row_step=1,
+                     bias=b.to(dev), out32=out, c_row_mul=u, c_row_off=p)
+        _check(out, ref, dtype, 2 * Cin, f"convT k{k} u{u}")
+
+
+def test_grouped_conv_batch(dev):
+    """Grouped Conv1d k31 g16 pad 15 over a batch of 2 (networks.py:70-76)."""
+    from usdm_amd import ops
+    dtype = torch.bfloat16
+    B, T, G, Cg, k = 2, 150, 4, 64, 31
+    C_ = G * Cg
+    x = _rand((B, C_, T), dtype, 11)
+    w = _rand((C_, Cg, k), dtype, 12, 0.1)
+    b = _rand((C_,), torch.float32, 13)
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), padding=k // 2, groups=G).permute(0, 2, 1)
+    A = x.permute(0, 2, 1).contiguous().to(dev)  # [B, T, C]
+    Wp = w.reshape(G, Cg, Cg, k).permute(0, 1, 3, 2).contiguous().reshape(G, Cg, k * Cg).to(dev)
+    out = torch.zeros((B, T, C_), device=dev)
+    ops.gemm(A, Wp, M=T, N=Cg, Kc=Cg, taps=k, lda=C_, rowsA=T, a_row_off=-(k // 2), a_row_step=1,
+             groups=G, batch=B, a_gstride=Cg, w_gstride=Cg * k * Cg, a_bstride=T * C_, c_gcol=Cg, c_bstride=T,
+             bias=b.to(dev), act=1, out32=out, ldc=C_)
+    _check(out, torch.nn.functional.gelu(ref), dtype, k * Cg, "grouped conv")
+
+
+def test_two_source_k(dev):
+    """Linear over cat[h, skip] without materialising the concat (networks.py:364)."""
+    from usdm_amd import ops
+    M, H = 100, 64
+    buf = _rand((2, M, H), torch.bfloat16, 14).to(dev)
+    W = _rand((H, 2 * H), torch.bfloat16, 15)
+    out = torch.zeros((M, H), device=dev)
+    ops.gemm(buf, W.to(dev), M=M, N=H, Kc=H, taps=2, lda=H, rowsA=M, a_tap_stride=M * H, out32=out)
+    ref = torch.cat([buf[0].cpu(), buf[1].cpu()], -1).double() @ W.double().T
+    _check(out, ref, torch.bfloat16, 2 * H, "two-source")
+
+
+def test_swiglu_and_qkv(dev):
+    from usdm_amd import ops
+    M, K, F = 70, 64, 64
+    A = _rand((M, K), torch.bfloat16, 16)
+    Wg, Wu = _rand((F, K), torch.bfloat16, 17, 0.3), _rand((F, K), torch.bfloat16, 18, 0.3)
+    Wp = torch.stack([Wg.reshape(F // 16, 16, K), Wu.reshape(F // 16, 16, K)], 1).reshape(2 * F, K).contiguous()
+    out = torch.zeros((M, F), device=dev)
+    ops.gemm(A.to(dev), Wp.to(dev), M=M, N=2 * F, Kc=K, act=3, out32=out, ldc=F)
+    g, u = A.double() @ Wg.double().T, A.double() @ Wu.double().T
+    _check(out, torch.nn.functional.silu(g) * u, torch.bfloat16, K, "swiglu")
+    # qkv head split
+    B, S, Hh, D = 2, 37, 2, 64
+    Spad = 64
+    A = _rand((B * S, K), torch.bfloat16, 19)
+    W = _rand((3 * Hh * D, K), torch.bfloat16, 20, 0.3)
+    q = torch.zeros((B, Hh, Spad, D), device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    v = torch.zeros((B, Hh, D, Spad), device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), M=B * S, N=3 * Hh * D, Kc=K, qkv=dict(S=S, Spad=Spad, H=Hh, D=D, q=q, k=k, v=v))
+    ref = (A.double() @ W.double().T).reshape(B, S, 3, Hh, D)
+    _check(q[:, :, :S].float(), ref[:, :, 0].permute(0, 2, 1, 3), torch.bfloat16, K, "q")
+    _check(k[:, :, :S].float(), ref[:, :, 1].permute(0, 2, 1, 3), torch.bfloat16, K, "k")
+    _check(v[:, :, :, :S].float(), ref[:, :, 2].permute(0, 2, 3, 1), torch.bfloat16, K, "v^T")

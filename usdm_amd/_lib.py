@@ -1,0 +1,60 @@
+"""ctypes binding of libusdm_hip.so (C-ABI declared in include/usdm_hip.h).
+
+No fallback: if the shared library is missing or an entry point is absent this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libusdm_hip.so")
+
+
+class UsdmError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -m usdm_amd.build` (hipcc --offload-arch=gfx950). "
+        "usdm_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+lib.usdm_last_error.restype = C.c_char_p
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_TANH = 0, 1, 3, 4
+EPI_PLAIN, EPI_QKV_HEADS = 0, 1
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("taps", C.c_int32), ("Kc", C.c_int32),
+        ("A", C.c_void_p), ("lda", C.c_int64), ("rowsA", C.c_int32),
+        ("a_row_mul", C.c_int32), ("a_row_off", C.c_int32), ("a_row_step", C.c_int32),
+        ("a_tap_stride", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("groups", C.c_int32), ("batch", C.c_int32),
+        ("a_gstride", C.c_int64), ("w_gstride", C.c_int64), ("a_bstride", C.c_int64),
+        ("c_gcol", C.c_int32), ("c_bstride", C.c_int64),
+        ("bias", C.c_void_p), ("alpha", C.c_float), ("act", C.c_int32), ("round_bf16", C.c_int32),
+        ("residual", C.c_void_p), ("res_dtype", C.c_int32), ("ldr", C.c_int64),
+        ("C32", C.c_void_p), ("C16", C.c_void_p), ("ldc", C.c_int64),
+        ("c_row_mul", C.c_int32), ("c_row_off", C.c_int32), ("transpose_out", C.c_int32), ("epi", C.c_int32),
+        ("qkv_S", C.c_int32), ("qkv_Spad", C.c_int32), ("qkv_H", C.c_int32), ("qkv_D", C.c_int32),
+        ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_v", C.c_void_p),
+    ]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise UsdmError(f"{what} failed (rc={rc}): {lib.usdm_last_error().decode()}")
+
+
+def _selfcheck():
+    assert lib.usdm_abi_version() >= 1
+    n = lib.usdm_sizeof_gemm_args()
+    if n != C.sizeof(GemmArgs):
+        raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
+
+
+_selfcheck()

@@ -1,0 +1,59 @@
+"""Builds libusdm_hip.so (all HIP kernels + the C-ABI) in-tree with hipcc for gfx950.
+
+Used by __graft_entry__.build(); the .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libusdm_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(HERE, "..", "include", "usdm_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    objs, jobs = [], []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(bdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, src):
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(OUT):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,65 @@
+// Shared device/host helpers for libusdm_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+
+// ---- error plumbing (thread-local last error, C-ABI returns int) -------------------------------
+void usdm_set_error(const char* fmt, ...);
+#define USDM_CHECK_ARG(cond, ...)                       \
+  do {                                                  \
+    if (!(cond)) {                                      \
+      usdm_set_error(__VA_ARGS__);                      \
+      return 2;                                         \
+    }                                                   \
+  } while (0)
+#define USDM_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e_ = (call);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      usdm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)
+#define USDM_LAUNCH_CHECK()                                                         \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      usdm_set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved by the plain cast) ---------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, ((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ---- wave64 reductions --------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
