@@ -83,6 +83,28 @@ typedef struct usdm_gemm_args {
 
 int usdm_gemm(const usdm_gemm_args* args, usdm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm / RMSNorm over channels of [rows][C] activations (one wave per row).
+ *   t = x (+ res);  [premask: rows s >= valid_len[b] zeroed first];  sum32/sum16 <- t (optional)
+ *   y = (t - mean) * rsqrt(var + eps) * gamma + beta     (rms: mean := 0, no beta)
+ *   y = act(y);  rows s >= valid_len[b] are written as zero
+ * Replaces nn.LayerNorm at networks.py:245-247,297,349; XLS-R LayerNorms; HF MistralRMSNorm.
+ * round_bf16 = 1 reproduces HF's bf16 rounding points: bf16(gamma * bf16(t * rstd)), and rounds
+ * t = x + res to bf16 (the bf16 residual stream of HF Mistral).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct usdm_norm_args {
+  const void* x; int32_t x_dtype; int64_t ldx;
+  const void* res; int32_t res_dtype; int64_t ldr;
+  const float* gamma; const float* beta; float eps;
+  int32_t rows, C;
+  int32_t rms, act, round_bf16, premask;
+  const int32_t* valid_len; int32_t rows_per_batch;
+  void* out32; void* out16; int64_t ldo;
+  void* sum32; void* sum16; int64_t lds;
+} usdm_norm_args;
+
+int usdm_norm(const usdm_norm_args* args, usdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

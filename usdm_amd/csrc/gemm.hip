@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
                 __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  __builtin_bit_cast(float, fa[i][e]), __builtin_bit_cast(float, fb[j][e]), acc[i][j], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+              // NB: bit_cast of a vector-element lvalue reads element 0; go through scalars.
+              const unsigned ua = fa[i][e], ub = fb[j][e];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub), acc[i][j], 0, 0, 0);
+            }
           }
         }
     }

@@ -1,0 +1,116 @@
+// LayerNorm / RMSNorm over the channel axis of channels-last activations: one wave per row.
+// Replaces nn.LayerNorm at networks.py:245-247,297 (Voicebox), the per-conv / per-layer LayerNorms
+// of the XLS-R encoder and HF MistralRMSNorm (third-party).
+// HBM-bound: each row is read once (kept in registers), written once per requested output.
+#include "common.h"
+#include "../../include/usdm_hip.h"
+
+namespace {
+constexpr int MAXP = 20;  // float4 pieces per lane: C <= 5120
+
+template <int NP>
+__global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int npieces = a.C >> 2;
+  float4 v[NP];
+  bool zero_row = false;
+  if (a.valid_len) {
+    const int b = row / a.rows_per_batch, s = row - b * a.rows_per_batch;
+    zero_row = s >= a.valid_len[b];
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = p * 64 + lane;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < npieces) {
+      if (a.x_dtype == USDM_F32) {
+        x = *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + idx * 4);
+      } else {
+        const uint2 r = *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + idx * 4);
+        x = make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
+      }
+      if (a.res) {
+        float4 r4;
+        if (a.res_dtype == USDM_F32) {
+          r4 = *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4);
+        } else {
+          const uint2 r = *(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + idx * 4);
+          r4 = make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
+        }
+        x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
+        if (a.round_bf16) { x.x = round_bf(x.x); x.y = round_bf(x.y); x.z = round_bf(x.z); x.w = round_bf(x.w); }
+      }
+      if (a.premask && zero_row) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.sum32) *(float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4) = x;
+      if (a.sum16) {
+        uint2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
+        *(uint2*)((bf16_t*)a.sum16 + (int64_t)row * a.lds + idx * 4) = o;
+      }
+    }
+    v[p] = x;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) s += (v[p].x + v[p].y) + (v[p].z + v[p].w);
+  const float invC = 1.0f / (float)a.C;
+  float mean = 0.f;
+  if (!a.rms) mean = wave_sum(s) * invC;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = p * 64 + lane;
+    if (idx < npieces) {
+      const float dx = v[p].x - mean, dy = v[p].y - mean, dz = v[p].z - mean, dw = v[p].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float var = wave_sum(q) * invC;
+  const float rstd = rsqrtf(var + a.eps);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = p * 64 + lane;
+    if (idx >= npieces) continue;
+    const float4 gm = *(const float4*)(a.gamma + idx * 4);
+    float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
+    float y[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = (y[e] - mean) * rstd;
+      if (a.round_bf16) t = round_bf(round_bf(t) * g4[e]);  // HF: weight * hidden.to(bf16)
+      else t = t * g4[e] + b4[e];
+      if (a.act == USDM_ACT_GELU) t = gelu_erf(t);
+      if (zero_row) t = 0.f;
+      y[e] = t;
+    }
+    if (a.out32) *(float4*)((float*)a.out32 + (int64_t)row * a.ldo + idx * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    if (a.out16) {
+      uint2 o; o.x = pack_bf2(y[0], y[1]); o.y = pack_bf2(y[2], y[3]);
+      *(uint2*)((bf16_t*)a.out16 + (int64_t)row * a.ldo + idx * 4) = o;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int usdm_norm(const usdm_norm_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->x && pa->gamma, "usdm_norm: null args");
+  const usdm_norm_args& a = *pa;
+  USDM_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.C <= MAXP * 256, "usdm_norm: C=%d must be a multiple of 4 and <= %d", a.C, MAXP * 256);
+  USDM_CHECK_ARG(a.rows > 0, "usdm_norm: rows");
+  USDM_CHECK_ARG(a.out32 || a.out16, "usdm_norm: no output");
+  USDM_CHECK_ARG(!a.valid_len || a.rows_per_batch > 0, "usdm_norm: rows_per_batch");
+  USDM_CHECK_ARG(a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.lds % 4 == 0, "usdm_norm: strides must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(a.rows, 4)), block(256);
+  const int np = cdiv(a.C, 256);
+  if (np <= 2) hipLaunchKernelGGL(norm_kernel<2>, grid, block, 0, st, a);
+  else if (np <= 5) hipLaunchKernelGGL(norm_kernel<5>, grid, block, 0, st, a);
+  else if (np <= 16) hipLaunchKernelGGL(norm_kernel<16>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(norm_kernel<MAXP>, grid, block, 0, st, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int usdm_sizeof_norm_args(void) { return (int)sizeof(usdm_norm_args); }
