@@ -105,6 +105,52 @@ typedef struct usdm_norm_args {
 
 int usdm_norm(const usdm_norm_args* args, usdm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused anti-aliased SnakeBeta: Activation1d(SnakeBeta) of the reference in one pass
+ * (vocoder/alias_free_torch/act.py:23-28, resample.py:25-33, filter.py:86-95,
+ *  vocoder/activations.py:107-120).  x is channels-last f32 [T][ldx]; channels >= Creal are padding
+ * and are written as zero.  fup/fdn: the 12 Kaiser-sinc taps of kaiser_sinc_filter1d(0.25,0.3,12)
+ * (filter.py:28-57) computed on the host.  L: time steps per thread (0 = choose).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct usdm_snake_args {
+  const float* x; int64_t ldx;
+  int32_t T, C, Creal, L;
+  const float* alpha; const float* beta; int32_t logscale;
+  float fup[12]; float fdn[12];
+  float* out32; void* out16; int64_t ldo;
+} usdm_snake_args;
+int usdm_aa_snake(const usdm_snake_args* args, usdm_stream_t stream);
+
+/* (a+b+c)*scale over n f32 elements (vocoder/models.py:198-204). n % 4 == 0. */
+int usdm_sum3_scale(const float* a, const float* b, const float* c, float scale, int64_t n,
+                    float* out32, void* out16_bf16, usdm_stream_t stream);
+
+/* channels-first f32 [B][C][T] -> channels-last [B][T][Cpad] (f32 and/or bf16), y = x*scale+shift,
+ * padded channels zero.  Mel de-normalisation + layout change (model_util.py:103-104). */
+int usdm_cf_to_cl(const float* x, int32_t B, int32_t C, int32_t T, int32_t Cpad, float scale, float shift,
+                  float* out32, void* out16_bf16, usdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash-style attention forward (bf16 MFMA, fp32 online softmax), nothing [S,S]-sized in memory.
+ *   mode 0: bidirectional, score += -slopes[h]*|i-j| (0 for key 0 if alibi_col0_zero), keys >= kv_len[b]
+ *           masked  -> Voicebox Attention.forward + Transformer.forward bias (networks.py:162-210,319-341)
+ *   mode 1: causal (key j visible iff j <= q_pos0 + i), GQA -> HF Mistral prefill attention
+ * Layouts (bf16, element strides): q[b][h][s][dh] via q_bs/q_hs/q_rs; k likewise with Hkv heads;
+ * vt = V^T [b][hk][dh][key] via v_bs/v_hs/v_ds; o[b][s][h*dh] via o_bs/o_rs.
+ * K/V^T must be allocated and finite up to Skv_alloc >= roundup(Skv,64) keys.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct usdm_attn_args {
+  int32_t mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_pos0, alibi_col0_zero;
+  float scale;
+  const void* q; int64_t q_bs, q_hs, q_rs;
+  const void* k; int64_t k_bs, k_hs, k_rs;
+  const void* vt; int64_t v_bs, v_hs, v_ds;
+  void* o; int64_t o_bs, o_rs;
+  const int32_t* kv_len;  /* [B] or NULL (= Skv) */
+  const float* slopes;    /* [Hq] or NULL */
+} usdm_attn_args;
+int usdm_attention(const usdm_attn_args* args, usdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,75 @@
+"""CPU: the oracle restatements reproduce the golden vectors produced by the reference itself."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import bigvgan_oracle as BO
+from oracle import units_oracle as UO
+from oracle import voicebox_oracle as VO
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(n):
+    return {k: torch.from_numpy(v) if v.ndim else v.item() for k, v in np.load(os.path.join(G, n)).items()}
+
+
+def _close(a, b, tol):
+    err = (a - b).abs().max().item()
+    assert err <= tol * (b.abs().max().item() + 1e-12), err
+
+
+def test_filter_taps_and_activation1d():
+    d = _load("bigvgan_act.npz")
+    taps = BO.aa_filter_taps()
+    assert torch.allclose(taps, d["taps"], atol=1e-7)
+    y = BO.activation1d(d["x"], d["alpha"], d["beta"], taps)
+    _close(y, d["y"], 1e-6)
+
+
+def test_bigvgan_small_and_full():
+    for name in ("bigvgan_small.npz", "bigvgan_full.npz"):
+        d = _load(name)
+        h = dict(BO.BIGVGAN_22K_80, upsample_initial_channel=int(d["c0"]))
+        sd = BO.random_state_dict(h, seed=int(d["seed"]))
+        wav = BO.bigvgan_forward(sd, h, d["mel"])
+        assert wav.shape == d["wav"].shape
+        _close(wav, d["wav"], 1e-5)
+        assert d["wav"].abs().mean() > 0.05  # fixture is not degenerate
+
+
+def test_voicebox_small():
+    from tests.golden.configs import SMALL_VB
+    d = _load("voicebox_small.npz")
+    cfg = SMALL_VB
+    sd = VO.random_state_dict(cfg, seed=int(d["seed"]))
+    est = VO.estimator_forward(sd, cfg, d["x"], d["y"], d["cond"], d["t"], d["lengths"])
+    _close(est, d["est"], 2e-5)
+    P = int(d["P"])
+    gen = VO.generate(sd, cfg, d["x"], d["cond"], d["lengths"], int(d["nt_h"]), list(d["noise_h"]), "heun", 1.0, True,
+                      torch.tensor([P]))
+    _close(gen, d["gen_h"], 1e-4)
+    gen = VO.generate(sd, cfg, d["x"], torch.zeros_like(d["cond"]), d["lengths"], int(d["nt_e"]), list(d["noise_e"]),
+                      "euler", float(d["gs_e"]), False)
+    _close(gen, d["gen_e"], 1e-4)
+
+
+def test_voicebox_full_width():
+    d = _load("voicebox_full.npz")
+    cfg = VO.VOICEBOX_CFG
+    sd = VO.random_state_dict(cfg, seed=int(d["seed"]))
+    S = d["y"].shape[-1]
+    est = VO.estimator_forward(sd, cfg, d["x"], torch.cat([d["y"]] * 2), torch.cat([torch.zeros_like(d["cond"]), d["cond"]]),
+                               torch.full((2, 1, 1), float(d["t"])), torch.tensor([S, S]))
+    _close(est, d["est"], 5e-5)
+
+
+def test_process_unit():
+    d = np.load(os.path.join(G, "process_unit.npz"))
+    for i in range(5):
+        out, new_len = UO.process_unit(d[f"u{i}"].tolist())
+        assert new_len == int(d[f"len{i}"])
+        assert out == d[f"o{i}"][0].tolist()
+    # frame counts the survey quotes: 500 -> 861, 149 -> 256
+    assert d["o3"].shape[1] == 861 and d["o2"].shape[1] == 256

@@ -45,6 +45,42 @@ class GemmArgs(C.Structure):
     ]
 
 
+class NormArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_dtype", C.c_int32), ("ldx", C.c_int64),
+        ("res", C.c_void_p), ("res_dtype", C.c_int32), ("ldr", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+        ("rows", C.c_int32), ("C", C.c_int32),
+        ("rms", C.c_int32), ("act", C.c_int32), ("round_bf16", C.c_int32), ("premask", C.c_int32),
+        ("valid_len", C.c_void_p), ("rows_per_batch", C.c_int32),
+        ("out32", C.c_void_p), ("out16", C.c_void_p), ("ldo", C.c_int64),
+        ("sum32", C.c_void_p), ("sum16", C.c_void_p), ("lds", C.c_int64),
+    ]
+
+
+class SnakeArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("T", C.c_int32), ("C", C.c_int32), ("Creal", C.c_int32), ("L", C.c_int32),
+        ("alpha", C.c_void_p), ("beta", C.c_void_p), ("logscale", C.c_int32),
+        ("fup", C.c_float * 12), ("fdn", C.c_float * 12),
+        ("out32", C.c_void_p), ("out16", C.c_void_p), ("ldo", C.c_int64),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("dh", C.c_int32), ("B", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
+        ("Sq", C.c_int32), ("Skv", C.c_int32), ("Skv_alloc", C.c_int32), ("q_pos0", C.c_int32),
+        ("alibi_col0_zero", C.c_int32), ("scale", C.c_float),
+        ("q", C.c_void_p), ("q_bs", C.c_int64), ("q_hs", C.c_int64), ("q_rs", C.c_int64),
+        ("k", C.c_void_p), ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
+        ("vt", C.c_void_p), ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_ds", C.c_int64),
+        ("o", C.c_void_p), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
+        ("kv_len", C.c_void_p), ("slopes", C.c_void_p),
+    ]
+
+
 def check(rc, what=""):
     if rc != 0:
         raise UsdmError(f"{what} failed (rc={rc}): {lib.usdm_last_error().decode()}")
@@ -55,6 +91,10 @@ def _selfcheck():
     n = lib.usdm_sizeof_gemm_args()
     if n != C.sizeof(GemmArgs):
         raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
+    for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs)):
+        n = getattr(lib, f"usdm_sizeof_{name}_args")()
+        if n != C.sizeof(cls):
+            raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")
 
 
 _selfcheck()

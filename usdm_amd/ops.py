@@ -3,11 +3,12 @@
 These exist for the parity tests and for the Python drop-ins; they add no arithmetic.
 """
 import ctypes as C
+import ctypes as C_
 
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, GemmArgs, check, lib
+from ._lib import BF16, F32, AttnArgs, GemmArgs, NormArgs, SnakeArgs, check, lib
 
 
 def _stream():
@@ -61,3 +62,49 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]
         a.qkv_q, a.qkv_k, a.qkv_v = _ptr(qkv["q"]), _ptr(qkv["k"]), _ptr(qkv["v"])
     check(lib.usdm_gemm(C.byref(a), _stream()), "usdm_gemm")
+
+
+def norm(x, gamma, beta=None, *, rows, C, eps=1e-5, res=None, rms=False, act=0, round_bf16=False, premask=False,
+         valid_len=None, rows_per_batch=0, out32=None, out16=None, sum32=None, sum16=None,
+         ldx=None, ldr=None, ldo=None, lds=None):
+    """usdm_norm: LayerNorm/RMSNorm over the last axis (see include/usdm_hip.h)."""
+    _need_cuda(x, gamma, beta, res, out32, out16, sum32, sum16, valid_len)
+    a = NormArgs()
+    a.x, a.x_dtype, a.ldx = _ptr(x), _dt(x), (ldx if ldx is not None else C)
+    a.res, a.res_dtype, a.ldr = _ptr(res), (_dt(res) if res is not None else F32), (ldr if ldr is not None else C)
+    a.gamma, a.beta, a.eps = _ptr(gamma), _ptr(beta), eps
+    a.rows, a.C = rows, C
+    a.rms, a.act, a.round_bf16, a.premask = int(rms), act, int(round_bf16), int(premask)
+    a.valid_len, a.rows_per_batch = _ptr(valid_len), rows_per_batch
+    a.out32, a.out16, a.ldo = _ptr(out32), _ptr(out16), (ldo if ldo is not None else C)
+    a.sum32, a.sum16, a.lds = _ptr(sum32), _ptr(sum16), (lds if lds is not None else C)
+    check(lib.usdm_norm(C_.byref(a), _stream()), "usdm_norm")
+
+
+def aa_snake(x, alpha, beta, fup, fdn, *, T, C, Creal=None, logscale=True, out32=None, out16=None, ldx=None, ldo=None, L=0):
+    """usdm_aa_snake: fused Activation1d(SnakeBeta) on channels-last f32 [T][C]."""
+    _need_cuda(x, alpha, beta, out32, out16)
+    a = SnakeArgs()
+    a.x, a.ldx = _ptr(x), (ldx if ldx is not None else C)
+    a.T, a.C, a.Creal, a.L = T, C, (Creal if Creal is not None else C), L
+    a.alpha, a.beta, a.logscale = _ptr(alpha), _ptr(beta), int(logscale)
+    for j in range(12):
+        a.fup[j] = float(fup[j])
+        a.fdn[j] = float(fdn[j])
+    a.out32, a.out16, a.ldo = _ptr(out32), _ptr(out16), (ldo if ldo is not None else C)
+    check(lib.usdm_aa_snake(C_.byref(a), _stream()), "usdm_aa_snake")
+
+
+def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_strides, k_strides, v_strides, o_strides,
+              scale=1.0, q_pos0=0, kv_len=None, slopes=None, alibi_col0_zero=True):
+    """usdm_attention (see include/usdm_hip.h for layouts)."""
+    _need_cuda(q, k, vt, o, kv_len, slopes)
+    a = AttnArgs()
+    a.mode, a.dh, a.B, a.Hq, a.Hkv, a.Sq, a.Skv, a.Skv_alloc = mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc
+    a.q_pos0, a.alibi_col0_zero, a.scale = q_pos0, int(alibi_col0_zero), scale
+    a.q, (a.q_bs, a.q_hs, a.q_rs) = _ptr(q), q_strides
+    a.k, (a.k_bs, a.k_hs, a.k_rs) = _ptr(k), k_strides
+    a.vt, (a.v_bs, a.v_hs, a.v_ds) = _ptr(vt), v_strides
+    a.o, (a.o_bs, a.o_rs) = _ptr(o), o_strides
+    a.kv_len, a.slopes = _ptr(kv_len), _ptr(slopes)
+    check(lib.usdm_attention(C_.byref(a), _stream()), "usdm_attention")
