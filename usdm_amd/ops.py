@@ -15,6 +15,41 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class Plan:
+    """A recorded sequence of C-ABI launches with their argument structs pre-built.
+
+    Python builds the structs once per shape; run() is then a tight loop of ctypes calls on the
+    current HIP stream (and is what gets captured into a hipGraph by usdm_amd.graph.GraphedPlan)."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []  # tensors that must outlive the plan (workspaces, packed weights)
+
+    def add(self, what, fn, *args):
+        self.calls.append((what, fn, args))
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def run(self):
+        st = _stream()
+        for what, fn, args in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, what)
+
+    def __len__(self):
+        return len(self.calls)
+
+
+def _go(plan, what, fn, *args):
+    if plan is not None:
+        plan.add(what, fn, *args)
+    else:
+        check(fn(*args, _stream()), what)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -37,7 +72,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
          a_tap_stride=0, ldw=None, groups=1, batch=1, a_gstride=0, w_gstride=0, a_bstride=0, c_gcol=0,
          c_bstride=0, bias=None, alpha=1.0, act=0, round_bf16=False, residual=None, ldr=0,
          out32=None, out16=None, ldc=None, c_row_mul=1, c_row_off=0, transpose_out=False,
-         qkv=None):
+         qkv=None, plan=None):
     """Raw launch of usdm_gemm; see include/usdm_hip.h for the meaning of every field."""
     _need_cuda(A, W, bias, residual, out32, out16)
     a = GemmArgs()
@@ -61,12 +96,12 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]
         a.qkv_q, a.qkv_k, a.qkv_v = _ptr(qkv["q"]), _ptr(qkv["k"]), _ptr(qkv["v"])
-    check(lib.usdm_gemm(C.byref(a), _stream()), "usdm_gemm")
+    _go(plan, "usdm_gemm", lib.usdm_gemm, C.byref(a))
 
 
 def norm(x, gamma, beta=None, *, rows, C, eps=1e-5, res=None, rms=False, act=0, round_bf16=False, premask=False,
          valid_len=None, rows_per_batch=0, out32=None, out16=None, sum32=None, sum16=None,
-         ldx=None, ldr=None, ldo=None, lds=None):
+         ldx=None, ldr=None, ldo=None, lds=None, plan=None):
     """usdm_norm: LayerNorm/RMSNorm over the last axis (see include/usdm_hip.h)."""
     _need_cuda(x, gamma, beta, res, out32, out16, sum32, sum16, valid_len)
     a = NormArgs()
@@ -78,10 +113,10 @@ def norm(x, gamma, beta=None, *, rows, C, eps=1e-5, res=None, rms=False, act=0, 
     a.valid_len, a.rows_per_batch = _ptr(valid_len), rows_per_batch
     a.out32, a.out16, a.ldo = _ptr(out32), _ptr(out16), (ldo if ldo is not None else C)
     a.sum32, a.sum16, a.lds = _ptr(sum32), _ptr(sum16), (lds if lds is not None else C)
-    check(lib.usdm_norm(C_.byref(a), _stream()), "usdm_norm")
+    _go(plan, "usdm_norm", lib.usdm_norm, C_.byref(a))
 
 
-def aa_snake(x, alpha, beta, fup, fdn, *, T, C, Creal=None, logscale=True, out32=None, out16=None, ldx=None, ldo=None, L=0):
+def aa_snake(x, alpha, beta, fup, fdn, *, T, C, Creal=None, logscale=True, out32=None, out16=None, ldx=None, ldo=None, L=0, plan=None):
     """usdm_aa_snake: fused Activation1d(SnakeBeta) on channels-last f32 [T][C]."""
     _need_cuda(x, alpha, beta, out32, out16)
     a = SnakeArgs()
@@ -92,11 +127,11 @@ def aa_snake(x, alpha, beta, fup, fdn, *, T, C, Creal=None, logscale=True, out32
         a.fup[j] = float(fup[j])
         a.fdn[j] = float(fdn[j])
     a.out32, a.out16, a.ldo = _ptr(out32), _ptr(out16), (ldo if ldo is not None else C)
-    check(lib.usdm_aa_snake(C_.byref(a), _stream()), "usdm_aa_snake")
+    _go(plan, "usdm_aa_snake", lib.usdm_aa_snake, C_.byref(a))
 
 
 def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_strides, k_strides, v_strides, o_strides,
-              scale=1.0, q_pos0=0, kv_len=None, slopes=None, alibi_col0_zero=True):
+              scale=1.0, q_pos0=0, kv_len=None, slopes=None, alibi_col0_zero=True, plan=None):
     """usdm_attention (see include/usdm_hip.h for layouts)."""
     _need_cuda(q, k, vt, o, kv_len, slopes)
     a = AttnArgs()
@@ -107,4 +142,18 @@ def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_stride
     a.vt, (a.v_bs, a.v_hs, a.v_ds) = _ptr(vt), v_strides
     a.o, (a.o_bs, a.o_rs) = _ptr(o), o_strides
     a.kv_len, a.slopes = _ptr(kv_len), _ptr(slopes)
-    check(lib.usdm_attention(C_.byref(a), _stream()), "usdm_attention")
+    _go(plan, "usdm_attention", lib.usdm_attention, C_.byref(a))
+
+
+def sum3_scale(a, b, c, scale, *, out32=None, out16=None, plan=None):
+    _need_cuda(a, b, c, out32, out16)
+    n = a.numel()
+    _go(plan, "usdm_sum3_scale", lib.usdm_sum3_scale, _ptr(a), _ptr(b), _ptr(c), C.c_float(scale), C.c_int64(n),
+        _ptr(out32), _ptr(out16))
+
+
+def cf_to_cl(x, *, B, C, T, Cpad, scale=1.0, shift=0.0, out32=None, out16=None, plan=None):
+    """channels-first f32 [B][C][T] -> channels-last [B][T][Cpad]."""
+    _need_cuda(x, out32, out16)
+    _go(plan, "usdm_cf_to_cl", lib.usdm_cf_to_cl, _ptr(x), C_.c_int32(B), C_.c_int32(C), C_.c_int32(T), C_.c_int32(Cpad),
+        C_.c_float(scale), C_.c_float(shift), _ptr(out32), _ptr(out16))
