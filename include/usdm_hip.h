@@ -151,6 +151,44 @@ typedef struct usdm_attn_args {
 } usdm_attn_args;
 int usdm_attention(const usdm_attn_args* args, usdm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Voicebox glue (dense math is usdm_gemm / usdm_attention / usdm_norm).
+ * ---------------------------------------------------------------------------------------------- */
+/* Estimator input assembly: embed(x)*sqrt(E) ++ y ++ cond, channels-last bf16 rows
+ * (networks.py:305-307), with the classifier-free-guidance batch doubling of voicebox.py:60-65
+ * done in place when dup == 2 (first B_in rows: null token, zero cond). */
+typedef struct usdm_vb_input_args {
+  const int64_t* ids;  /* [B_in][S] */
+  const float* y;      /* [B_in][F][S] */
+  const float* cond;   /* [B_in][F][S] */
+  const void* table;   /* bf16 [n_tokens+1][E], already multiplied by sqrt(E) */
+  int32_t B_in, dup, S, E, F, null_id, use_cond;
+  void* out; int64_t ldo; /* bf16 [B_in*dup][S][ldo] */
+} usdm_vb_input_args;
+int usdm_vb_build_input(const usdm_vb_input_args* args, usdm_stream_t stream);
+
+/* Sinusoidal time token (SinusoidalPosEmb, networks.py:13-28) into row 0 of each batch of h:
+ * [sin(1000*t*freqs), cos(1000*t*freqs)], freqs[H/2] = exp(arange(H/2) * -ln(1e4)/(H/2-1)) from the host. */
+int usdm_vb_time_token(const float* t, int32_t t_stride, const float* freqs, int32_t Bx, int32_t H,
+                       int64_t rows_per_batch, float* h32, void* h16_bf16, usdm_stream_t stream);
+
+/* One elementwise solver update (voicebox.py:66-72 CFG, :83-90 Euler, :112-131 Heun):
+ *   v = cfg ? vc + gs*(vc - vu) : vout
+ *   mode 0: v1 <- v ; zn = z + dt*v          mode 1: zn = z + dt*(v1 + v)/2
+ *   if eps: zn[.., s < P] = c_eps*eps + c_cond*cond   (prompt re-noising, :115-117,:126-128)
+ *   z_in <- zn (estimator input), z_commit <- zn (solver state), t_cur[0..t_count) <- t_next */
+typedef struct usdm_vb_solver_args {
+  const float* vout;  /* [B*(cfg?2:1)][F][S] */
+  const float* z; float* v1; const float* eps; const float* cond;
+  float* z_in; float* z_commit; float* t_cur;
+  int32_t B, F, S, P, cfg, mode, t_count;
+  float gs, dt, c_eps, c_cond, t_next;
+} usdm_vb_solver_args;
+int usdm_vb_solver_step(const usdm_vb_solver_args* args, usdm_stream_t stream);
+
+/* device-to-device async copy (graph-capturable plumbing) */
+int usdm_copy_bytes(void* dst, const void* src, int64_t nbytes, usdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

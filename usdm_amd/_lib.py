@@ -81,6 +81,25 @@ class AttnArgs(C.Structure):
     ]
 
 
+class VbInputArgs(C.Structure):
+    _fields_ = [
+        ("ids", C.c_void_p), ("y", C.c_void_p), ("cond", C.c_void_p), ("table", C.c_void_p),
+        ("B_in", C.c_int32), ("dup", C.c_int32), ("S", C.c_int32), ("E", C.c_int32), ("F", C.c_int32),
+        ("null_id", C.c_int32), ("use_cond", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+    ]
+
+
+class VbSolverArgs(C.Structure):
+    _fields_ = [
+        ("vout", C.c_void_p), ("z", C.c_void_p), ("v1", C.c_void_p), ("eps", C.c_void_p), ("cond", C.c_void_p),
+        ("z_in", C.c_void_p), ("z_commit", C.c_void_p), ("t_cur", C.c_void_p),
+        ("B", C.c_int32), ("F", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("cfg", C.c_int32), ("mode", C.c_int32),
+        ("t_count", C.c_int32),
+        ("gs", C.c_float), ("dt", C.c_float), ("c_eps", C.c_float), ("c_cond", C.c_float), ("t_next", C.c_float),
+    ]
+
+
 def check(rc, what=""):
     if rc != 0:
         raise UsdmError(f"{what} failed (rc={rc}): {lib.usdm_last_error().decode()}")
@@ -91,7 +110,8 @@ def _selfcheck():
     n = lib.usdm_sizeof_gemm_args()
     if n != C.sizeof(GemmArgs):
         raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
-    for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs)):
+    for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
+                      ("vb_solver", VbSolverArgs)):
         n = getattr(lib, f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

@@ -1,0 +1,108 @@
+// Voicebox-specific glue kernels (everything dense runs in gemm.hip / attn.hip / norm.hip).
+#include "common.h"
+#include "../../include/usdm_hip.h"
+
+namespace {
+
+// A[bx][s][0:E] = table[id] (pre-scaled by sqrt(E) at pack time), [E:E+F] = y[:, s], [E+F:E+2F] = cond[:, s]
+// (networks.py:305-307).  dup == 2 is the classifier-free-guidance doubling of voicebox.py:60-65:
+// the first B_in rows of the batch are the unconditional copy (null token, zero cond).
+__global__ void vb_build_input_kernel(const usdm_vb_input_args a) {
+  const int s = blockIdx.x, bx = blockIdx.y;
+  const int b = bx % a.B_in, half = bx / a.B_in;
+  const bool uncond = (a.dup == 2) && (half == 0);
+  const int64_t id = uncond ? (int64_t)a.null_id : a.ids[(int64_t)b * a.S + s];
+  bf16_t* out = (bf16_t*)a.out + ((int64_t)bx * a.S + s) * a.ldo;
+  const bf16_t* row = (const bf16_t*)a.table + id * a.E;
+  for (int c = threadIdx.x * 8; c < a.E; c += blockDim.x * 8) *(u32x4*)(out + c) = *(const u32x4*)(row + c);
+  for (int c = threadIdx.x; c < a.F; c += blockDim.x) {
+    const int64_t src = ((int64_t)b * a.F + c) * a.S + s;
+    out[a.E + c] = f2bf(a.y[src]);
+    out[a.E + a.F + c] = f2bf((uncond || !a.use_cond) ? 0.f : a.cond[src]);
+  }
+  for (int c = a.E + 2 * a.F + threadIdx.x; c < a.ldo; c += blockDim.x) out[c] = 0;
+}
+
+// sinusoidal time token into row 0 of every batch (networks.py:19-28, 312-313)
+__global__ void vb_time_token_kernel(const float* t, int t_stride, const float* freqs, int Bx, int H,
+                                     int64_t rows_per_batch, float* h32, bf16_t* h16) {
+  const int b = blockIdx.x;
+  const int half = H / 2;
+  const float tv = t[b * t_stride];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float v = (1000.0f * tv) * freqs[i];  // freqs = exp(arange(half) * -ln(1e4)/(half-1)), host-made
+    const float sv = sinf(v), cv = cosf(v);
+    const int64_t o = (int64_t)b * rows_per_batch * H;
+    h32[o + i] = sv;
+    h32[o + half + i] = cv;
+    if (h16) { h16[o + i] = f2bf(sv); h16[o + half + i] = f2bf(cv); }
+  }
+}
+
+// One elementwise pass of the CFM solvers (voicebox.py:66-72 CFG combine, :83-90 Euler, :112-131 Heun)
+__global__ void vb_solver_kernel(const usdm_vb_solver_args a) {
+  const int64_t n = (int64_t)a.B * a.F * a.S;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = (int)(i % a.S);
+  float v;
+  if (a.cfg) {
+    const float vu = a.vout[i], vc = a.vout[n + i];
+    v = vc + a.gs * (vc - vu);
+  } else {
+    v = a.vout[i];
+  }
+  float zn;
+  if (a.mode == 0) {  // Euler / Heun predictor
+    if (a.v1) a.v1[i] = v;
+    zn = a.z[i] + a.dt * v;
+  } else {            // Heun corrector
+    zn = a.z[i] + (a.dt * (a.v1[i] + v)) / 2.0f;
+  }
+  if (a.eps && s < a.P) zn = a.c_eps * a.eps[i] + a.c_cond * a.cond[i];
+  if (a.z_in) a.z_in[i] = zn;
+  if (a.z_commit) a.z_commit[i] = zn;
+  if (i == 0 && a.t_cur) {
+    for (int b = 0; b < a.t_count; ++b) a.t_cur[b] = a.t_next;
+  }
+}
+}  // namespace
+
+extern "C" int usdm_vb_build_input(const usdm_vb_input_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->ids && pa->y && pa->table && pa->out, "usdm_vb_build_input: null args");
+  const usdm_vb_input_args& a = *pa;
+  USDM_CHECK_ARG(a.B_in > 0 && (a.dup == 1 || a.dup == 2) && a.S > 0 && a.E % 8 == 0 && a.ldo >= a.E + 2 * a.F && a.ldo % 8 == 0,
+                 "usdm_vb_build_input: bad sizes");
+  USDM_CHECK_ARG(!a.use_cond || a.cond, "usdm_vb_build_input: cond missing");
+  hipLaunchKernelGGL(vb_build_input_kernel, dim3(a.S, a.B_in * a.dup), dim3(256), 0, (hipStream_t)stream, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_vb_time_token(const float* t, int32_t t_stride, const float* freqs, int32_t Bx, int32_t H,
+                                  int64_t rows_per_batch, float* h32, void* h16, usdm_stream_t stream) {
+  USDM_CHECK_ARG(t && freqs && h32 && Bx > 0 && H % 2 == 0, "usdm_vb_time_token: bad args");
+  hipLaunchKernelGGL(vb_time_token_kernel, dim3(Bx), dim3(256), 0, (hipStream_t)stream, t, t_stride, freqs, Bx, H,
+                     rows_per_batch, h32, (bf16_t*)h16);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_vb_solver_step(const usdm_vb_solver_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->vout && pa->z, "usdm_vb_solver_step: null args");
+  const usdm_vb_solver_args& a = *pa;
+  USDM_CHECK_ARG(a.mode == 0 || (a.mode == 1 && a.v1), "usdm_vb_solver_step: corrector needs v1");
+  USDM_CHECK_ARG(!a.eps || a.cond, "usdm_vb_solver_step: re-noising needs cond");
+  const int64_t n = (int64_t)a.B * a.F * a.S;
+  hipLaunchKernelGGL(vb_solver_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_copy_bytes(void* dst, const void* src, int64_t nbytes, usdm_stream_t stream) {
+  USDM_CHECK_ARG(dst && src && nbytes >= 0, "usdm_copy_bytes: bad args");
+  USDM_HIP(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int usdm_sizeof_vb_input_args(void) { return (int)sizeof(usdm_vb_input_args); }
+extern "C" int usdm_sizeof_vb_solver_args(void) { return (int)sizeof(usdm_vb_solver_args); }

@@ -8,7 +8,7 @@ import ctypes as C_
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, AttnArgs, GemmArgs, NormArgs, SnakeArgs, check, lib
+from ._lib import BF16, F32, AttnArgs, GemmArgs, NormArgs, SnakeArgs, VbInputArgs, VbSolverArgs, check, lib
 
 
 def _stream():
@@ -157,3 +157,34 @@ def cf_to_cl(x, *, B, C, T, Cpad, scale=1.0, shift=0.0, out32=None, out16=None, 
     _need_cuda(x, out32, out16)
     _go(plan, "usdm_cf_to_cl", lib.usdm_cf_to_cl, _ptr(x), C_.c_int32(B), C_.c_int32(C), C_.c_int32(T), C_.c_int32(Cpad),
         C_.c_float(scale), C_.c_float(shift), _ptr(out32), _ptr(out16))
+
+
+def vb_build_input(ids, y, cond, table, out, *, B_in, dup, S, E, F, null_id, use_cond, ldo, plan=None):
+    _need_cuda(ids, y, cond, table, out)
+    a = VbInputArgs()
+    a.ids, a.y, a.cond, a.table = _ptr(ids), _ptr(y), _ptr(cond), _ptr(table)
+    a.B_in, a.dup, a.S, a.E, a.F, a.null_id, a.use_cond = B_in, dup, S, E, F, null_id, int(use_cond)
+    a.out, a.ldo = _ptr(out), ldo
+    _go(plan, "usdm_vb_build_input", lib.usdm_vb_build_input, C_.byref(a))
+
+
+def vb_time_token(t, freqs, h32, h16, *, Bx, H, rows_per_batch, t_stride=1, plan=None):
+    _need_cuda(t, freqs, h32, h16)
+    _go(plan, "usdm_vb_time_token", lib.usdm_vb_time_token, _ptr(t), C_.c_int32(t_stride), _ptr(freqs), C_.c_int32(Bx),
+        C_.c_int32(H), C_.c_int64(rows_per_batch), _ptr(h32), _ptr(h16))
+
+
+def vb_solver_step(vout, z, *, B, F, S, mode, dt, cfg=False, gs=0.0, v1=None, eps=None, cond=None, P=0, c_eps=0.0,
+                   c_cond=0.0, z_in=None, z_commit=None, t_cur=None, t_count=0, t_next=0.0, plan=None):
+    _need_cuda(vout, z, v1, eps, cond, z_in, z_commit, t_cur)
+    a = VbSolverArgs()
+    a.vout, a.z, a.v1, a.eps, a.cond = _ptr(vout), _ptr(z), _ptr(v1), _ptr(eps), _ptr(cond)
+    a.z_in, a.z_commit, a.t_cur = _ptr(z_in), _ptr(z_commit), _ptr(t_cur)
+    a.B, a.F, a.S, a.P, a.cfg, a.mode, a.t_count = B, F, S, P, int(cfg), mode, t_count
+    a.gs, a.dt, a.c_eps, a.c_cond, a.t_next = gs, dt, c_eps, c_cond, t_next
+    _go(plan, "usdm_vb_solver_step", lib.usdm_vb_solver_step, C_.byref(a))
+
+
+def copy_bytes(dst, src, nbytes, plan=None):
+    _need_cuda(dst, src)
+    _go(plan, "usdm_copy_bytes", lib.usdm_copy_bytes, _ptr(dst), _ptr(src), C_.c_int64(nbytes))

@@ -1,0 +1,270 @@
+"""Token-Voicebox estimator drop-in (reference: src/decoder/voicebox/model/networks.py:270-374).
+
+`Transformer` keeps the reference's constructor and state-dict keys; its modules only hold parameters.
+forward(x, y, cond, t, lengths) runs entirely in libusdm_hip.so:
+
+  usdm_vb_build_input  embed*sqrt(E) ++ y ++ cond (+ CFG doubling)          networks.py:305-307
+  usdm_gemm            proj_in (Conv1d k=1), rows 1..S of each batch         :299,307
+  usdm_vb_time_token   sinusoidal t token in row 0                           :312-313
+  usdm_gemm (grouped)  2 x PositionalConvEmbedding (k31,g16,weight-norm)+GELU :343-346
+  usdm_norm            + residual, LayerNorm                                 :346-348
+  per layer: usdm_gemm QKV (head-split epilogue, V written transposed) -> usdm_attention (ALiBi,
+             column-0 rule, key mask) -> usdm_gemm out_proj(+bias+residual) -> usdm_norm ->
+             usdm_gemm FFN1(+GELU) -> usdm_gemm FFN2(+residual) -> usdm_norm     :236-266
+  usdm_gemm two-source K for the U-Net skip Linear(cat[h, skip])             :362-364
+  usdm_gemm proj_out, transposed store, token 0 dropped                      :372-374
+
+Numerics: GEMM/attention operands bf16 on the MFMA cores, fp32 accumulation; residual stream,
+LayerNorm, softmax statistics and solver state fp32.
+"""
+import math
+
+import torch
+from torch import nn
+
+from ... import ops
+from ..._lib import ACT_GELU
+from ...graph import GraphedPlan
+
+
+def get_slopes(n: int):
+    """ALiBi slopes (reference: networks.py:99-115)."""
+    def p2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n).is_integer():
+        return p2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return p2(c) + get_slopes(2 * c)[0::2][: n - c]
+
+
+class SinusoidalPosEmb(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0, "SinusoidalPosEmb requires dim to be even"
+        self.dim = dim
+
+
+class PositionalConvEmbedding(nn.Module):
+    def __init__(self, hidden_size, convpos_width, convpos_groups):
+        super().__init__()
+        conv = nn.Conv1d(hidden_size, hidden_size, kernel_size=convpos_width, padding=convpos_width // 2, groups=convpos_groups)
+        self.conv = nn.utils.parametrizations.weight_norm(conv, name="weight", dim=2)
+
+
+class Attention(nn.Module):
+    def __init__(self, embed_dim, num_heads, dropout=0.0, is_decoder=False, bias=True, is_causal=False):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.scaling = self.head_dim ** -0.5
+        self.k_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.v_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, activation_dropout, hidden_size, intermediate_size, hidden_dropout):
+        super().__init__()
+        self.intermediate_dense = nn.Linear(hidden_size, intermediate_size)
+        self.output_dense = nn.Linear(intermediate_size, hidden_size)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, hidden_size, intermediate_size, num_attention_heads, attention_dropout, activation_dropout, hidden_dropout):
+        super().__init__()
+        self.attention = Attention(hidden_size, num_attention_heads, dropout=attention_dropout)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-5)
+        self.feed_forward = FeedForward(activation_dropout, hidden_size, intermediate_size, hidden_dropout)
+        self.final_layer_norm = nn.LayerNorm(hidden_size, eps=1e-5)
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class Transformer(nn.Module):
+    def __init__(self, n_feats, n_tokens, embedding_dim, hidden_size, intermediate_size, num_attention_heads,
+                 num_hidden_layers, convpos_width, convpos_groups, convpos_depth, attention_dropout=0.0,
+                 activation_dropout=0.1, hidden_dropout=0.0):
+        super().__init__()
+        self.n_feats, self.n_tok = n_feats, n_tokens
+        self.hidden_size, self.embedding_dim = hidden_size, embedding_dim
+        self.intermediate_size = intermediate_size
+        self.num_heads, self.num_hidden_layers = num_attention_heads, num_hidden_layers
+        self.convpos_width, self.convpos_groups = convpos_width, convpos_groups
+        if hidden_size // num_attention_heads != 64:
+            raise NotImplementedError("usdm_attention (bidirectional ALiBi) is built for head_dim 64, the token-Voicebox setting")
+        if hidden_size % 32 or intermediate_size % 32 or embedding_dim % 8 or (hidden_size // convpos_groups) % 32:
+            raise NotImplementedError("channel counts must be multiples of 32 for the MFMA tap-GEMM")
+        if convpos_width % 2 == 0:
+            raise NotImplementedError("even convpos_width (SamePadLayer trim) is not used by token-Voicebox")
+        self.embed = nn.Embedding(n_tokens, embedding_dim)
+        self.time_embed = SinusoidalPosEmb(hidden_size)
+        self.proj_in = nn.Conv1d(2 * n_feats + embedding_dim, hidden_size, kernel_size=1)
+        self.pos_conv_embeds = nn.ModuleList([PositionalConvEmbedding(hidden_size, convpos_width, convpos_groups) for _ in range(convpos_depth)])
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-5)
+        self.layers = nn.ModuleList([EncoderLayer(hidden_size, intermediate_size, num_attention_heads, attention_dropout, activation_dropout, hidden_dropout) for _ in range(num_hidden_layers)])
+        self.skip_connections_layers = nn.ModuleList([nn.Linear(2 * hidden_size, hidden_size) for _ in range(num_hidden_layers // 2)])
+        self.proj_out = nn.Conv1d(hidden_size, n_feats, kernel_size=1)
+        self._packed, self._plans = None, {}
+
+    def invalidate(self):
+        self._packed, self._plans = None, {}
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    # ------------------------------------------------------------------ packing (load-time plumbing)
+    def _pack(self, dev):
+        bf, f32 = torch.bfloat16, torch.float32
+        H, E, F_ = self.hidden_size, self.embedding_dim, self.n_feats
+        g = lambda t: t.detach().to(dev, f32)
+        P = {}
+        P["table"] = (g(self.embed.weight) * math.sqrt(E)).to(bf).contiguous()
+        kin = E + 2 * F_
+        kinp = _pad32(kin)
+        w = torch.zeros(H, kinp, device=dev)
+        w[:, :kin] = g(self.proj_in.weight)[:, :, 0]
+        P["w_in"], P["b_in"], P["kinp"] = w.to(bf).contiguous(), g(self.proj_in.bias).contiguous(), kinp
+        P["pos"] = []
+        G, k = self.convpos_groups, self.convpos_width
+        cg = H // G
+        for pc in self.pos_conv_embeds:
+            w = g(pc.conv.weight)  # parametrised weight: g * v / ||v||  (weight-norm over dim 2)
+            wp = w.reshape(G, cg, cg, k).permute(0, 1, 3, 2).contiguous().reshape(G, cg, k * cg)
+            P["pos"].append((wp.to(bf).contiguous(), g(pc.conv.bias).contiguous()))
+        P["ln0"] = (g(self.layer_norm.weight).contiguous(), g(self.layer_norm.bias).contiguous())
+        P["layers"] = []
+        for lay in self.layers:
+            at, sc = lay.attention, lay.attention.scaling
+            wqkv = torch.cat([g(at.q_proj.weight) * sc, g(at.k_proj.weight), g(at.v_proj.weight)], 0)
+            bqkv = torch.cat([g(at.q_proj.bias) * sc, g(at.k_proj.bias), g(at.v_proj.bias)], 0)
+            P["layers"].append(dict(
+                wqkv=wqkv.to(bf).contiguous(), bqkv=bqkv.contiguous(),
+                wo=g(at.out_proj.weight).to(bf).contiguous(), bo=g(at.out_proj.bias).contiguous(),
+                ln1=(g(lay.layer_norm.weight).contiguous(), g(lay.layer_norm.bias).contiguous()),
+                w1=g(lay.feed_forward.intermediate_dense.weight).to(bf).contiguous(), b1=g(lay.feed_forward.intermediate_dense.bias).contiguous(),
+                w2=g(lay.feed_forward.output_dense.weight).to(bf).contiguous(), b2=g(lay.feed_forward.output_dense.bias).contiguous(),
+                ln2=(g(lay.final_layer_norm.weight).contiguous(), g(lay.final_layer_norm.bias).contiguous())))
+        P["skips"] = [(g(l.weight).to(bf).contiguous(), g(l.bias).contiguous()) for l in self.skip_connections_layers]
+        P["w_out"], P["b_out"] = g(self.proj_out.weight)[:, :, 0].to(bf).contiguous(), g(self.proj_out.bias).contiguous()
+        P["slopes"] = torch.tensor(get_slopes(self.num_heads), dtype=f32, device=dev)
+        half = H // 2
+        emb = math.log(10000) / (half - 1)
+        P["freqs"] = torch.exp(torch.arange(half).float() * -emb).to(dev)
+        return P
+
+    # ------------------------------------------------------------------ plan
+    def build_plan(self, B_in, S1, dup, use_cond, dev):
+        """Pre-built launch sequence for one estimator evaluation at batch B_in*dup, S1 frames."""
+        if self._packed is None:
+            self._packed = self._pack(dev)
+        P = self._packed
+        bf, f32 = torch.bfloat16, torch.float32
+        H, I, F_, E, nh, L = self.hidden_size, self.intermediate_size, self.n_feats, self.embedding_dim, self.num_heads, self.num_hidden_layers
+        Bx, S = B_in * dup, S1 + 1
+        Spad = (S + 63) // 64 * 64
+        R = Bx * S
+        plan = ops.Plan()
+        Z = lambda *s, dt=f32: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        io = dict(ids=Z(B_in, S1, dt=torch.int64), y=Z(B_in, F_, S1), cond=Z(B_in, F_, S1), t=Z(Bx), out=Z(Bx, F_, S1),
+                  kv_len=plan.hold(torch.full((Bx,), S, dtype=torch.int32, device=dev)))
+        ain = Z(Bx * S1, P["kinp"], dt=bf)
+        h32, tmp32 = Z(R, H), Z(R, H)
+        arena = Z(L // 2 + 2, R, H, dt=bf)   # slot 0: current h, slot 1: skip-linear output, 2..: skip stack
+        pc16 = Z(R, H, dt=bf)
+        q, k = Z(Bx, nh, Spad, 64, dt=bf), Z(Bx, nh, Spad, 64, dt=bf)
+        vt = Z(Bx, nh, 64, Spad, dt=bf)
+        o16, f16 = Z(R, H, dt=bf), Z(R, I, dt=bf)
+
+        ops.vb_build_input(io["ids"], io["y"], io["cond"], P["table"], ain, B_in=B_in, dup=dup, S=S1, E=E, F=F_,
+                           null_id=self.n_tok - 1, use_cond=use_cond, ldo=P["kinp"], plan=plan)
+        cur = arena[0]
+        ops.vb_time_token(io["t"], P["freqs"], h32, cur, Bx=Bx, H=H, rows_per_batch=S, plan=plan)
+        ops.gemm(ain, P["w_in"], M=S1, N=H, Kc=P["kinp"], lda=P["kinp"], rowsA=S1, batch=Bx, a_bstride=S1 * P["kinp"],
+                 c_bstride=S, c_row_off=1, bias=P["b_in"], out32=h32, out16=cur, ldc=H, plan=plan)
+        G, kw = self.convpos_groups, self.convpos_width
+        cg = H // G
+        src = cur
+        for i, (w, b) in enumerate(P["pos"]):
+            last = i == len(P["pos"]) - 1
+            ops.gemm(src, w, M=S, N=cg, Kc=cg, taps=kw, lda=H, rowsA=S, a_row_off=-(kw // 2), a_row_step=1, groups=G, batch=Bx,
+                     a_gstride=cg, w_gstride=cg * kw * cg, a_bstride=S * H, c_gcol=cg, c_bstride=S, bias=b, act=ACT_GELU,
+                     out32=tmp32 if last else None, out16=None if last else pc16, ldc=H, plan=plan)
+            src = pc16
+        # h = LN(posconv + residual): skip stack bottom is this output
+        slot = 2
+        ops.norm(tmp32, *P["ln0"], rows=R, C=H, res=h32, out32=h32, out16=arena[slot], plan=plan)
+        cur = arena[slot]
+        stack = [slot]
+        slot += 1
+        slopes = P["slopes"]
+
+        def layer(lp, cur, out16):
+            ops.gemm(cur, lp["wqkv"], M=R, N=3 * H, Kc=H, bias=lp["bqkv"], plan=plan,
+                     qkv=dict(S=S, Spad=Spad, H=nh, D=64, q=q, k=k, v=vt))
+            ops.attention(q, k, vt, o16, mode=0, dh=64, B=Bx, Hq=nh, Hkv=nh, Sq=S, Skv=S, Skv_alloc=Spad,
+                          q_strides=(nh * Spad * 64, Spad * 64, 64), k_strides=(nh * Spad * 64, Spad * 64, 64),
+                          v_strides=(nh * 64 * Spad, 64 * Spad, Spad), o_strides=(S * H, H), scale=1.0,
+                          kv_len=io["kv_len"], slopes=slopes, alibi_col0_zero=True, plan=plan)
+            ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=tmp32, plan=plan)
+            ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan)
+            ops.gemm(pc16, lp["w1"], M=R, N=I, Kc=H, bias=lp["b1"], act=ACT_GELU, out16=f16, plan=plan)
+            ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=tmp32, plan=plan)
+            ops.norm(tmp32, *lp["ln2"], rows=R, C=H, out32=h32, out16=out16, plan=plan)
+
+        for n in range(L):
+            lp = P["layers"][n]
+            if n < L // 2:
+                push = n < L // 2 - 1
+                dst = arena[slot] if push else arena[0]
+                layer(lp, cur, dst)
+                cur = dst
+                if push:
+                    stack.append(slot)
+                    slot += 1
+            else:
+                sk = stack.pop()
+                w, b = P["skips"][n - L // 2]
+                assert cur.data_ptr() == arena[0].data_ptr()
+                ops.gemm(arena, w, M=R, N=H, Kc=H, taps=2, lda=H, rowsA=R, a_tap_stride=sk * R * H, bias=b,
+                         out32=h32, out16=arena[1], plan=plan)
+                layer(lp, arena[1], arena[0])
+                cur = arena[0]
+        assert not stack
+        # proj_out over rows 1..S of each batch, stored transposed as [Bx][F][S1]
+        ops.gemm(cur[1:], P["w_out"], M=S1, N=F_, Kc=H, lda=H, rowsA=S1, batch=Bx, a_bstride=S * H, c_bstride=F_ * S1,
+                 bias=P["b_out"], out32=io["out"], ldc=S1, transpose_out=True, plan=plan)
+        return plan, io
+
+    def get_plan(self, B_in, S1, dup, use_cond, dev):
+        key = (B_in, S1, dup, bool(use_cond), dev.index)
+        if key not in self._plans:
+            plan, io = self.build_plan(B_in, S1, dup, use_cond, dev)
+            self._plans[key] = (GraphedPlan(plan), io)
+        return self._plans[key]
+
+    @torch.no_grad()
+    def forward(self, x, y, cond, t, lengths):
+        """x int64 [B,S], y/cond f32 [B,F,S], t f32 [B,1,1], lengths int64 [B] -> f32 [B,F,S]
+        (reference: networks.py:302-374)."""
+        if not y.is_cuda:
+            raise RuntimeError("Voicebox estimator (usdm_amd) runs on the MI355X only; there is no CPU fallback")
+        B, _, S1 = y.shape
+        if not bool((lengths.to("cpu") == S1).all()):
+            raise NotImplementedError("ragged batches (lengths < frames) are not implemented on the HIP path yet")
+        gp, io = self.get_plan(B, S1, 1, True, y.device)
+        io["ids"].copy_(x)
+        io["y"].copy_(y)
+        io["cond"].copy_(cond)
+        io["t"].copy_(t.reshape(B))
+        gp.run()
+        return io["out"].clone()

@@ -1,0 +1,135 @@
+"""CFM solvers + Voicebox drop-in (reference: src/decoder/voicebox/model/voicebox.py:18-176).
+
+Same class names, constructor, `.generate(...)` signature, `.estimator`, `.n_tokens`, state-dict keys
+(`estimator.*`).  Additions: `noise=` lets the caller supply the N(0,1) draws the reference takes
+with randn_like (device RNG != CPU RNG; the parity tests feed the reference's draws), and
+`from_pretrained` loads from a local directory (config.json + model.safetensors / pytorch_model.bin).
+The estimator evaluation is one hipGraph replay; the solver update is one fused elementwise kernel.
+"""
+import json
+import os
+
+import torch
+from torch import nn
+
+from ... import ops
+from .networks import Transformer
+
+
+class BaseModule(nn.Module):
+    @property
+    def nparams(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+class CFM(BaseModule):
+    def __init__(self, solver, sigma_min):
+        super().__init__()
+        self.solver = solver
+        self.sigma_min = sigma_min
+        self.estimator = None
+
+    def forward(self, x, mask, x1, lengths):
+        raise NotImplementedError("training loss (voicebox.py:28-49) is outside the inference hot path")
+
+    @torch.no_grad()
+    def generate(self, x, cond, cond_lengths, n_timesteps, solver="euler", gradient_scale=0.0, speech_prompt=False,
+                 prompt_lengths=None, noise=None):
+        """x int64 [B,S], cond f32 [B,80,S], cond_lengths int64 [B] -> f32 [B,80,S]
+        (reference: voicebox.py:140-150 with solve_euler :74-99 / solve_heun :101-138 and the CFG of :51-72)."""
+        if solver not in ("euler", "heun"):
+            return None  # the reference falls through and returns None for unknown solvers
+        if not cond.is_cuda:
+            raise RuntimeError("Voicebox.generate (usdm_amd) runs on the MI355X only; there is no CPU fallback")
+        dev = cond.device
+        B, F_, S = cond.shape
+        if not bool((cond_lengths.to("cpu") == S).all()):
+            raise NotImplementedError("ragged batches (lengths < frames) are not implemented on the HIP path yet")
+        heun = solver == "heun"
+        n = (n_timesteps + 1) // 2 if heun else n_timesteps
+        P = int(prompt_lengths[0]) if speech_prompt else 0
+        n_noise = 1 + ((2 * n - 1 if heun else n) if speech_prompt else 0)
+        if noise is None:
+            noise = torch.randn(n_noise, B, F_, S, device=dev, dtype=torch.float32)
+        else:
+            noise = (torch.stack(list(noise)) if not torch.is_tensor(noise) else noise).to(dev, torch.float32).contiguous()
+            if noise.shape != (n_noise, B, F_, S):
+                raise ValueError(f"noise must have shape {(n_noise, B, F_, S)}, got {tuple(noise.shape)}")
+        cfg = gradient_scale > 0
+        gp, io = self.estimator.get_plan(B, S, 2 if cfg else 1, bool(speech_prompt), dev)
+        io["ids"].copy_(x)
+        io["cond"].copy_(cond)
+        condf = io["cond"]
+        Z = noise[0].clone()
+        v1 = torch.empty_like(Z)
+        io["y"].copy_(Z)
+        # time grid on the host in fp32, computed exactly as the reference does (voicebox.py:145,102,135)
+        t_span = torch.linspace(0, 1, n + 1)
+        t, dt = t_span[0], t_span[1] - t_span[0]
+        io["t"].fill_(float(t))
+        Bx = B * (2 if cfg else 1)
+        k = 1
+        common = dict(B=B, F=F_, S=S, cfg=cfg, gs=float(gradient_scale), z_in=io["y"], t_cur=io["t"], t_count=Bx, cond=condf, P=P)
+        for steps in range(1, n + 1):
+            gp.run()
+            t = t + dt
+            c_eps, c_cond = float(1 - (1 - self.sigma_min) * t), float(t)
+            last = steps == n
+            do_corr = heun and not last
+            eps = None
+            if speech_prompt:
+                eps, k = noise[k], k + 1
+            ops.vb_solver_step(io["out"], Z, mode=0, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
+                               z_commit=None if do_corr else Z, t_next=float(t), **common)
+            if do_corr:
+                gp.run()
+                eps = None
+                if speech_prompt:
+                    eps, k = noise[k], k + 1
+                ops.vb_solver_step(io["out"], Z, mode=1, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
+                                   z_commit=Z, t_next=float(t), **common)
+            if not last:
+                dt = t_span[steps + 1] - t
+        return Z
+
+
+class Voicebox(CFM):
+    def __init__(self, n_feats, n_tokens, embedding_dim, hidden_size, intermediate_size, num_attention_heads,
+                 num_hidden_layers, convpos_width, convpos_groups, convpos_depth, attention_dropout, activation_dropout,
+                 hidden_dropout, solver, sigma_min):
+        super().__init__(solver=solver, sigma_min=sigma_min)
+        self.n_tokens = n_tokens
+        self._init_kwargs = dict(n_feats=n_feats, n_tokens=n_tokens, embedding_dim=embedding_dim, hidden_size=hidden_size,
+                                 intermediate_size=intermediate_size, num_attention_heads=num_attention_heads,
+                                 num_hidden_layers=num_hidden_layers, convpos_width=convpos_width, convpos_groups=convpos_groups,
+                                 convpos_depth=convpos_depth, attention_dropout=attention_dropout,
+                                 activation_dropout=activation_dropout, hidden_dropout=hidden_dropout, solver=solver,
+                                 sigma_min=sigma_min)
+        self.estimator = Transformer(n_feats, n_tokens + 1, embedding_dim, hidden_size, intermediate_size, num_attention_heads,
+                                     num_hidden_layers, convpos_width, convpos_groups, convpos_depth, attention_dropout,
+                                     activation_dropout, hidden_dropout)
+
+    # hub-mixin surface, local directories only (no network in this environment)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, cache_dir=None, **kw):
+        d = pretrained_model_name_or_path
+        if not os.path.isdir(d):
+            raise FileNotFoundError(f"{d}: only local directories can be loaded (no network); expected config.json + weights")
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        model = cls(**cfg)
+        st = os.path.join(d, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(sd)
+        return model
+
+    def save_pretrained(self, save_directory):
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(self._init_kwargs, f, indent=2)
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, "model.safetensors"))
