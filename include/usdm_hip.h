@@ -189,6 +189,78 @@ int usdm_vb_solver_step(const usdm_vb_solver_args* args, usdm_stream_t stream);
 /* device-to-device async copy (graph-capturable plumbing) */
 int usdm_copy_bytes(void* dst, const void* src, int64_t nbytes, usdm_stream_t stream);
 
+/* process_unit (util/model_util.py:50-54): out[f] = mode of repeat_interleave(units, rep)[f*hop:(f+1)*hop],
+ * ties -> smallest id; nframes = floor(n*rep/hop).  int64 in / int64 out. */
+int usdm_process_unit(const int64_t* units, int32_t n, int32_t rep, int32_t hop, int64_t* out, int32_t nframes,
+                      usdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mistral-7B speech-text LLM (third-party arithmetic of the reference: HF transformers
+ * MistralForCausalLM + GenerationMixin.generate, call sites src/inference.py:63-83, load :116-124).
+ * Prefill uses usdm_gemm / usdm_norm / usdm_attention(mode 1); the kernels below are the rest.
+ * ---------------------------------------------------------------------------------------------- */
+/* Batch-1 GEMV y = W x over bf16 weights [N][ldw] (nn.Linear layout), HBM-streaming:
+ *   norm_w != NULL : x is the raw residual stream; RMSNorm(x)*norm_w is applied first (HF rounding)
+ *   act == USDM_ACT_SWIGLU : rows packed in blocks of 32 = 16 gate + 16 up; output N/2 = silu(g)*u
+ *   residual       : y += residual[n] (bf16)             round_bf16 : HF bf16 rounding points
+ *   part_val/idx   : lm_head mode — per-block (max, argmax) of the bf16-rounded logits with ban[n]==1
+ *                    excluded (bad_words_ids of inference.py:51-53); y32 (optional) receives the logits */
+typedef struct usdm_gemv_args {
+  const void* W; int64_t ldw; int32_t N, K;
+  const void* x;
+  const float* norm_w; float eps;
+  int32_t act, round_bf16;
+  const void* residual;
+  void* y16; float* y32;
+  const uint8_t* ban; float* part_val; int32_t* part_idx;
+  int32_t idx_offset; /* added to the row index stored in part_idx (vocab-parallel shards) */
+} usdm_gemv_args;
+int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
+int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
+
+/* Device-resident greedy-decode state so that a decode step is replayable as one hipGraph. */
+typedef struct usdm_decode_state {
+  int32_t* next_token;  /* [1] token fed to the next step                     */
+  int32_t* out_tokens;  /* [max_out] generated ids                            */
+  int32_t* step;        /* [1] number of generated tokens so far              */
+  int32_t* pos;         /* [1] number of tokens in the KV cache               */
+  int32_t max_out, id_offset, advance_pos;
+} usdm_decode_state;
+/* arg-max over the per-block partials (ties -> lowest id = torch.argmax on the masked logits; with
+ * do_sample=True, top_k=1 the reference samples among exact ties, of which this is one outcome). */
+int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
+                      const usdm_decode_state* st, usdm_stream_t stream);
+
+/* out[r][:] = table[ids[r]][:] (bf16 rows; ids == NULL -> single row from *next_token) */
+int usdm_embed_rows(const void* table, const int64_t* ids, const int32_t* next_token, int32_t n, int32_t Hd,
+                    void* out, usdm_stream_t stream);
+
+/* Prefill: HF apply_rotary_pos_emb (bf16 rounding) in place on q,k of qkv[S][(Hq+2Hkv)*128]; roped K and
+ * V appended to the caches [Hkv][ctx_max][128]; V also written transposed to vt[Hkv][128][vt_ld] for
+ * usdm_attention.  cos/sin: bf16 [max_pos][64] built on the host as HF's MistralRotaryEmbedding does. */
+typedef struct usdm_rope_args {
+  void* qkv; int64_t ld; int32_t S, pos0, Hq, Hkv, ctx_max, max_pos;
+  const uint16_t* cos; const uint16_t* sin;
+  void* kcache; void* vcache; void* vt; int64_t vt_ld;
+} usdm_rope_args;
+int usdm_rope_cache(const usdm_rope_args* args, usdm_stream_t stream);
+
+/* Decode attention for ONE new token (GQA, head_dim 128), context split over NS workgroups per kv head
+ * + combine.  Ropes q/k of qkv[(Hq+2Hkv)*128] at position *pos, appends K,V to the caches, writes
+ * out[Hq*128] bf16.  Softmax in fp32, P rounded to bf16 for PV (flash-attention-2 semantics). */
+typedef struct usdm_attn_decode_args {
+  const void* qkv; const int32_t* pos;
+  int32_t Hq, Hkv, ctx_max, NS; float scale;
+  const uint16_t* cos; const uint16_t* sin;
+  void* kcache; void* vcache;
+  float* pm; float* pl; float* po; /* scratch [Hq][NS], [Hq][NS], [Hq][NS][128] */
+  void* out;
+} usdm_attn_decode_args;
+int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
+
+/* h = bf16(h + bf16(delta)) : residual add after a tensor-parallel all-reduce of f32 partial sums */
+int usdm_residual_add(void* h_bf16, const float* delta, int32_t n, usdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,38 @@ def test_process_unit():
         assert out == d[f"o{i}"][0].tolist()
     # frame counts the survey quotes: 500 -> 861, 149 -> 256
     assert d["o3"].shape[1] == 861 and d["o2"].shape[1] == 256
+
+
+def test_mistral_oracle_vs_installed_transformers():
+    """The LLM arithmetic of the reference is third-party HF code; pin the restatement against the
+    transformers build present in this image (version skew vs the reference's 4.40.2 is documented)."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    from oracle import mistral_oracle as MO
+    cfg = dict(MO.MISTRAL_7B_USDM, vocab_size=300, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+               num_attention_heads=4, num_key_value_heads=2, head_dim=64)
+    hf_cfg = transformers.MistralConfig(
+        vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+        num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+        num_key_value_heads=cfg["num_key_value_heads"], head_dim=cfg["head_dim"], rms_norm_eps=cfg["rms_norm_eps"],
+        rope_theta=cfg["rope_theta"], max_position_embeddings=4096, sliding_window=4096, attn_implementation="eager",
+        tie_word_embeddings=False)
+    ids = torch.randint(0, 300, (1, 17), generator=torch.Generator().manual_seed(1))
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 3e-2)):
+        sd = MO.random_state_dict(cfg, seed=3, dtype=dtype)
+        m = transformers.MistralForCausalLM(hf_cfg).to(dtype).eval()
+        m.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            ref = m(ids).logits[0].float()
+        got, _ = MO.forward(sd, cfg, ids[0])
+        _close(got, ref, tol)
+    # greedy generate with a ban mask == HF generate(do_sample=True, top_k=1) on the same model (fp32: no ties)
+    sd = MO.random_state_dict(cfg, seed=3, dtype=torch.float32)
+    m = transformers.MistralForCausalLM(hf_cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    bad = [[i] for i in range(0, 150)]
+    with torch.no_grad():
+        hf = m.generate(input_ids=ids, max_length=17 + 12, do_sample=True, top_k=1, top_p=1.0, temperature=1.0,
+                        bad_words_ids=bad, eos_token_id=299, pad_token_id=0)
+    mine = MO.greedy_generate(sd, cfg, ids[0], 12, bad_words_ids=bad, eos_token_id=299)
+    assert hf[0].tolist() == mine

@@ -100,6 +100,42 @@ class VbSolverArgs(C.Structure):
     ]
 
 
+class GemvArgs(C.Structure):
+    _fields_ = [
+        ("W", C.c_void_p), ("ldw", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("x", C.c_void_p), ("norm_w", C.c_void_p), ("eps", C.c_float),
+        ("act", C.c_int32), ("round_bf16", C.c_int32),
+        ("residual", C.c_void_p), ("y16", C.c_void_p), ("y32", C.c_void_p),
+        ("ban", C.c_void_p), ("part_val", C.c_void_p), ("part_idx", C.c_void_p), ("idx_offset", C.c_int32),
+    ]
+
+
+class DecodeState(C.Structure):
+    _fields_ = [
+        ("next_token", C.c_void_p), ("out_tokens", C.c_void_p), ("step", C.c_void_p), ("pos", C.c_void_p),
+        ("max_out", C.c_int32), ("id_offset", C.c_int32), ("advance_pos", C.c_int32),
+    ]
+
+
+class RopeArgs(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("ld", C.c_int64), ("S", C.c_int32), ("pos0", C.c_int32), ("Hq", C.c_int32),
+        ("Hkv", C.c_int32), ("ctx_max", C.c_int32), ("max_pos", C.c_int32),
+        ("cos", C.c_void_p), ("sin", C.c_void_p),
+        ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("vt", C.c_void_p), ("vt_ld", C.c_int64),
+    ]
+
+
+class AttnDecodeArgs(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("pos", C.c_void_p),
+        ("Hq", C.c_int32), ("Hkv", C.c_int32), ("ctx_max", C.c_int32), ("NS", C.c_int32), ("scale", C.c_float),
+        ("cos", C.c_void_p), ("sin", C.c_void_p),
+        ("kcache", C.c_void_p), ("vcache", C.c_void_p),
+        ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
 def check(rc, what=""):
     if rc != 0:
         raise UsdmError(f"{what} failed (rc={rc}): {lib.usdm_last_error().decode()}")
@@ -111,8 +147,9 @@ def _selfcheck():
     if n != C.sizeof(GemmArgs):
         raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
-                      ("vb_solver", VbSolverArgs)):
-        n = getattr(lib, f"usdm_sizeof_{name}_args")()
+                      ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
+                      ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs)):
+        n = getattr(lib, f"usdm_sizeof_{name}" if name == "decode_state" else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")
 

@@ -1,0 +1,491 @@
+// Mistral-7B decode/prefill kernels other than the shared GEMM / flash-attention / norm kernels.
+//
+// The decode step is HBM-bound (14.3 GB of bf16 weights per token at batch 1), so the design rule is:
+// every weight byte is read exactly once, 16 B per lane, non-temporal, many loads in flight, and
+// everything else (RMSNorm, residual add, SwiGLU, ban-mask + argmax) is fused into the GEMV that
+// produces or consumes the vector.  Rounding points follow HF transformers' bf16 Mistral
+// (third-party arithmetic of the reference): every Linear output, RMSNorm, RoPE
+// product and residual add is rounded to bf16; logits are bf16 values compared in fp32.
+#include "common.h"
+#include "../../include/usdm_hip.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned a = w[i], b = x[i];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMV: y = W x, W bf16 [N][ldw] row-major (the nn.Linear layout), one workgroup per 16 output rows
+// (32 packed rows for SwiGLU), wave = 4 rows at a time, lanes stride K in 16-B pieces.
+// ---------------------------------------------------------------------------------------------
+constexpr int GV_ROWS = 16;
+
+__global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = (bf16_t*)smem;                       // [Kpad] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int Kpad = (K + 511) & ~511;
+  __shared__ float red[8];
+
+  // ---- stage x into LDS (optionally fused RMSNorm with HF rounding)
+  const bf16_t* xg = (const bf16_t*)a.x;
+  if (a.norm_w) {
+    float ss = 0.f;
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      const u32x4 v = *(const u32x4*)(xg + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf2f(v[e] & 0xffff), hi = bf2f(v[e] >> 16);
+        ss += lo * lo + hi * hi;
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float rstd = rsqrtf(tot / (float)K + a.eps);
+    for (int i = tid * 8; i < Kpad; i += 256 * 8) {
+      u32x4 o = {0, 0, 0, 0};
+      if (i < K) {
+        const u32x4 v = *(const u32x4*)(xg + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf2f(v[e] & 0xffff), hi = bf2f(v[e] >> 16);
+          const float nlo = round_bf(round_bf(lo * rstd) * a.norm_w[i + 2 * e]);
+          const float nhi = round_bf(round_bf(hi * rstd) * a.norm_w[i + 2 * e + 1]);
+          o[e] = pack_bf2(nlo, nhi);
+        }
+      }
+      *(u32x4*)(xs + i) = o;
+    }
+  } else {
+    for (int i = tid * 8; i < Kpad; i += 256 * 8) {
+      u32x4 v = {0, 0, 0, 0};
+      if (i < K) v = *(const u32x4*)(xg + i);
+      *(u32x4*)(xs + i) = v;
+    }
+  }
+  __syncthreads();
+
+  const bool glu = a.act == USDM_ACT_SWIGLU;
+  const int rows_per_block = glu ? 2 * GV_ROWS : GV_ROWS;
+  const int rb = blockIdx.x * rows_per_block;
+  // the 4 rows of this wave; for GLU: rows (g0, g1, u0, u1) = gate rows 2w,2w+1 ... handled as two passes
+  const int npass = glu ? 2 : 1;
+  float outv[4] = {0.f, 0.f, 0.f, 0.f};
+  float gatev[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pass = 0; pass < npass; ++pass) {
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = rb + pass * GV_ROWS + wave * 4 + j;
+    const u32x4* wp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rr = r[j] < a.N ? r[j] : a.N - 1;
+      wp[j] = (const u32x4*)((const bf16_t*)a.W + (int64_t)rr * a.ldw) + lane;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nfull = K >> 9;
+    int it = 0;
+    for (; it + 2 <= nfull; it += 2) {
+      u32x4 w0[4], w1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w0[j] = __builtin_nontemporal_load(wp[j] + it * 64);
+        w1[j] = __builtin_nontemporal_load(wp[j] + (it + 1) * 64);
+      }
+      const u32x4 x0 = *(const u32x4*)(xs + (it * 64 + lane) * 8);
+      const u32x4 x1 = *(const u32x4*)(xs + ((it + 1) * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = dot8(w1[j], x1, dot8(w0[j], x0, acc[j]));
+    }
+    for (; it < nfull; ++it) {
+      const u32x4 x0 = *(const u32x4*)(xs + (it * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = dot8(__builtin_nontemporal_load(wp[j] + it * 64), x0, acc[j]);
+    }
+    if ((nfull << 9) + lane * 8 < K) {  // K tail (K % 8 == 0)
+      const u32x4 x0 = *(const u32x4*)(xs + (nfull * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = dot8(__builtin_nontemporal_load(wp[j] + nfull * 64), x0, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if (glu && pass == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gatev[j] = acc[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) outv[j] = acc[j];
+    }
+  }
+
+  // ---- epilogue (lane 0 of each wave owns the wave's 4 outputs)
+  if (a.part_val) {  // lm_head: bf16-rounded logits, ban mask, per-block arg-max (ties -> lowest id)
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = rb + wave * 4 + j;
+      if (n < a.N && !(a.ban && a.ban[n])) {
+        const float v = round_bf(outv[j]);
+        if (a.y32) { if (lane == 0) a.y32[n] = v; }
+        if (v > bv) { bv = v; bi = n; }
+      } else if (n < a.N && a.y32 && lane == 0) {
+        a.y32[n] = -INFINITY;
+      }
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (sv[w] > bv) { bv = sv[w]; bi = si[w]; }
+      a.part_val[blockIdx.x] = bv;
+      a.part_idx[blockIdx.x] = bi == 0x7fffffff ? bi : bi + a.idx_offset;
+    }
+    return;
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (glu) {
+      const int nout = blockIdx.x * GV_ROWS + wave * 4 + j;
+      const int ngate = rb + wave * 4 + j;
+      if (ngate >= a.N) continue;
+      float o;
+      if (a.round_bf16) {
+        const float gt = round_bf(gatev[j]), up = round_bf(outv[j]);
+        o = round_bf(round_bf(gt / (1.0f + __expf(-gt))) * up);
+      } else {
+        o = (gatev[j] / (1.0f + __expf(-gatev[j]))) * outv[j];
+      }
+      if (a.y16) ((bf16_t*)a.y16)[nout] = f2bf(o);
+      if (a.y32) a.y32[nout] = o;
+    } else {
+      const int n = rb + wave * 4 + j;
+      if (n >= a.N) continue;
+      float v = outv[j];
+      if (a.round_bf16) v = round_bf(v);
+      if (a.residual) {
+        v += bf2f(((const bf16_t*)a.residual)[n]);
+        if (a.round_bf16) v = round_bf(v);
+      }
+      if (a.y16) ((bf16_t*)a.y16)[n] = f2bf(v);
+      if (a.y32) a.y32[n] = v;
+    }
+  }
+}
+
+// final arg-max over the per-block partials; advances the device-side decode state
+__global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, usdm_decode_state st) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    const float v = pv[i];
+    const int id = pi[i];
+    if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = sv[threadIdx.x + s];
+      const int id = si[threadIdx.x + s];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && id < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = id; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int tok = si[0] + st.id_offset;
+    const int step = *st.step;
+    *st.next_token = tok;
+    if (step < st.max_out) st.out_tokens[step] = tok;
+    *st.step = step + 1;
+    if (st.advance_pos) *st.pos = *st.pos + 1;
+  }
+}
+
+// h[0:Hd] = E[token] (bf16 row copy)  — nn.Embedding of HF MistralModel
+__global__ void embed_kernel(const bf16_t* E, const int64_t* ids, const int* next_token, int n, int Hd, bf16_t* out) {
+  const int r = blockIdx.x;
+  const int64_t id = ids ? ids[r] : (int64_t)(*next_token);
+  const u32x4* src = (const u32x4*)(E + id * Hd);
+  u32x4* dst = (u32x4*)(out + (int64_t)r * Hd);
+  for (int i = threadIdx.x; i < Hd / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE (HF apply_rotary_pos_emb in bf16) helpers.  cos/sin tables are bf16 [maxpos][64].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+  // o1 = x1*cos + (-x2)*sin ; o2 = x2*cos + x1*sin ; every product and sum rounded to bf16
+  o1 = round_bf(round_bf(x1 * c) + round_bf(-x2 * s));
+  o2 = round_bf(round_bf(x2 * c) + round_bf(x1 * s));
+}
+
+// prefill: in-place RoPE of q,k inside qkv [S][(Hq+2Hkv)*128]; K,V appended to the caches; V^T scratch
+__global__ void rope_cache_kernel(const usdm_rope_args a) {
+  const int s = blockIdx.x, hh = blockIdx.y;  // hh over Hq + 2*Hkv heads
+  const int d = threadIdx.x;                  // 0..63
+  const int pos = a.pos0 + s;
+  bf16_t* row = (bf16_t*)a.qkv + (int64_t)s * a.ld + hh * 128;
+  const float c = bf2f(a.cos[(int64_t)pos * 64 + d]), sn = bf2f(a.sin[(int64_t)pos * 64 + d]);
+  if (hh < a.Hq) {
+    float o1, o2;
+    rope_pair(bf2f(row[d]), bf2f(row[d + 64]), c, sn, o1, o2);
+    row[d] = f2bf(o1); row[d + 64] = f2bf(o2);
+  } else if (hh < a.Hq + a.Hkv) {
+    const int kh = hh - a.Hq;
+    float o1, o2;
+    rope_pair(bf2f(row[d]), bf2f(row[d + 64]), c, sn, o1, o2);
+    bf16_t* kc = (bf16_t*)a.kcache + ((int64_t)kh * a.ctx_max + pos) * 128;
+    kc[d] = f2bf(o1); kc[d + 64] = f2bf(o2);
+  } else {
+    const int vh = hh - a.Hq - a.Hkv;
+    bf16_t* vc = (bf16_t*)a.vcache + ((int64_t)vh * a.ctx_max + pos) * 128;
+    vc[d] = row[d]; vc[d + 64] = row[d + 64];
+    if (a.vt) {
+      bf16_t* vt = (bf16_t*)a.vt + (int64_t)vh * 128 * a.vt_ld;
+      vt[(int64_t)d * a.vt_ld + s] = row[d];
+      vt[(int64_t)(d + 64) * a.vt_ld + s] = row[d + 64];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode attention, split over the context: grid (Hkv, NS).  Each block ropes the new q (G heads of
+// its kv head) and the new k itself, so no block depends on another block's cache write.
+// ---------------------------------------------------------------------------------------------
+constexpr int DA_KMAX = 256;  // max keys per split
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode_args a) {
+  __shared__ float qs[G][128];
+  __shared__ float knew[128], vnew[128];
+  __shared__ float sc[G][DA_KMAX];
+  __shared__ float red[8][G][128];
+  __shared__ float lsum[G], lmax[G];
+  const int kh = blockIdx.x, sp = blockIdx.y, NS = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = *a.pos;
+  const int ctx = pos + 1;
+  const int chunk = (ctx + NS - 1) / NS;
+  const int k0 = sp * chunk, k1 = min(ctx, k0 + chunk);
+  const int nk = max(0, k1 - k0);
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  // ---- rope q (G heads) and the new k; stash v
+  for (int i = tid; i < (G + 1) * 64; i += 256) {
+    const int hsel = i >> 6, d = i & 63;
+    const float c = bf2f(a.cos[(int64_t)pos * 64 + d]), sn = bf2f(a.sin[(int64_t)pos * 64 + d]);
+    const bf16_t* src = hsel < G ? qkv + (kh * G + hsel) * 128 : qkv + (a.Hq + kh) * 128;
+    float o1, o2;
+    rope_pair(bf2f(src[d]), bf2f(src[d + 64]), c, sn, o1, o2);
+    if (hsel < G) { qs[hsel][d] = o1; qs[hsel][d + 64] = o2; }
+    else { knew[d] = o1; knew[d + 64] = o2; }
+  }
+  if (tid < 128) vnew[tid] = bf2f(qkv[(a.Hq + a.Hkv + kh) * 128 + tid]);
+  __syncthreads();
+  const bf16_t* Kc = (const bf16_t*)a.kcache + (int64_t)kh * a.ctx_max * 128;
+  const bf16_t* Vc = (const bf16_t*)a.vcache + (int64_t)kh * a.ctx_max * 128;
+  if (sp == 0 && tid < 128) {  // designated writer of the new cache row
+    ((bf16_t*)a.kcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
+    ((bf16_t*)a.vcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
+  }
+  // ---- scores: 8 lanes per key, 16 d each
+  {
+    const int j = lane & 7, gk = (wave << 3) + (lane >> 3);  // key slot within a 32-key sweep
+    float qr[G][16];
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) qr[h][e] = qs[h][j * 16 + e];
+    for (int kk = gk; kk < nk; kk += 32) {
+      const int ki = k0 + kk;
+      float kv[16];
+      if (ki == pos) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kv[e] = knew[j * 16 + e];
+      } else {
+        const u32x4 r0 = *(const u32x4*)(Kc + (int64_t)ki * 128 + j * 16);
+        const u32x4 r1 = *(const u32x4*)(Kc + (int64_t)ki * 128 + j * 16 + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kv[2 * e] = bf2f(r0[e] & 0xffff); kv[2 * e + 1] = bf2f(r0[e] >> 16);
+          kv[8 + 2 * e] = bf2f(r1[e] & 0xffff); kv[8 + 2 * e + 1] = bf2f(r1[e] >> 16);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s = fmaf(qr[h][e], kv[e], s);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (j == 0) sc[h][kk] = s * a.scale;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax statistics per head (wave h <-> head h when G <= 4)
+  for (int h = wave; h < G; h += 4) {
+    float m = -1e30f;
+    for (int kk = lane; kk < nk; kk += 64) m = fmaxf(m, sc[h][kk]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int kk = lane; kk < nk; kk += 64) {
+      const float p = __expf(sc[h][kk] - m);
+      l += p;
+      sc[h][kk] = round_bf(p);  // P is bf16 for the PV product (flash-attention semantics), l stays fp32
+    }
+    l = wave_sum(l);
+    if (lane == 0) { lsum[h] = l; lmax[h] = m; }
+  }
+  __syncthreads();
+  // ---- PV: thread = (4 d's, key lane)
+  {
+    const int d4 = (tid & 31) * 4, kl = tid >> 5;
+    float acc[G][4];
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
+    for (int kk = kl; kk < nk; kk += 8) {
+      const int ki = k0 + kk;
+      float v[4];
+      if (ki == pos) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = vnew[d4 + e];
+      } else {
+        const u32x2 r = *(const u32x2*)(Vc + (int64_t)ki * 128 + d4);
+        v[0] = bf2f(r[0] & 0xffff); v[1] = bf2f(r[0] >> 16); v[2] = bf2f(r[1] & 0xffff); v[3] = bf2f(r[1] >> 16);
+      }
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        const float p = sc[h][kk];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[kl][h][d4 + e] = acc[h][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < G * 128; i += 256) {
+    const int h = i >> 7, d = i & 127;
+    float s = 0.f;
+#pragma unroll
+    for (int kl = 0; kl < 8; ++kl) s += red[kl][h][d];
+    const int hq = kh * G + h;
+    a.po[((int64_t)hq * NS + sp) * 128 + d] = s;
+    if (d == 0) {
+      a.pm[hq * NS + sp] = nk > 0 ? lmax[h] : -1e30f;
+      a.pl[hq * NS + sp] = nk > 0 ? lsum[h] : 0.f;
+    }
+  }
+}
+
+__global__ void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out) {
+  const int hq = blockIdx.x, d = threadIdx.x;  // 128 threads
+  float m = -1e30f;
+  for (int s = 0; s < NS; ++s) m = fmaxf(m, pm[hq * NS + s]);
+  float l = 0.f, o = 0.f;
+  for (int s = 0; s < NS; ++s) {
+    const float w = __expf(pm[hq * NS + s] - m);
+    l += pl[hq * NS + s] * w;
+    o += po[((int64_t)hq * NS + s) * 128 + d] * w;
+  }
+  out[hq * 128 + d] = f2bf(o / l);
+}
+
+// h = bf16(h + bf16(delta))  — residual add after a tensor-parallel all-reduce of fp32 partial sums
+__global__ void residual_add_kernel(bf16_t* h, const float* delta, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i] = f2bf(bf2f(h[i]) + round_bf(delta[i]));
+}
+}  // namespace
+
+extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->W && pa->x, "usdm_gemv: null args");
+  const usdm_gemv_args& a = *pa;
+  USDM_CHECK_ARG(a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "usdm_gemv: bad N/K/ldw");
+  USDM_CHECK_ARG(a.K <= 16384, "usdm_gemv: K too large for the LDS-resident input vector");
+  const bool glu = a.act == USDM_ACT_SWIGLU;
+  USDM_CHECK_ARG(!glu || a.N % 32 == 0, "usdm_gemv: swiglu needs N %% 32 == 0");
+  USDM_CHECK_ARG(a.y16 || a.y32 || a.part_val, "usdm_gemv: no output");
+  USDM_CHECK_ARG(!a.part_val || a.part_idx, "usdm_gemv: part_idx missing");
+  const int rows = glu ? 2 * GV_ROWS : GV_ROWS;
+  const int Kpad = (a.K + 511) & ~511;
+  hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(a.N, rows)), dim3(256), Kpad * 2, (hipStream_t)stream, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int usdm_gemv_nblocks(int32_t N, int32_t act) { return cdiv(N, act == USDM_ACT_SWIGLU ? 2 * GV_ROWS : GV_ROWS); }
+
+extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
+                                 const usdm_decode_state* st, usdm_stream_t stream) {
+  USDM_CHECK_ARG(part_val && part_idx && nparts > 0 && st && st->next_token && st->out_tokens && st->step && st->pos,
+                 "usdm_argmax_final: bad args");
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_embed_rows(const void* table, const int64_t* ids, const int32_t* next_token, int32_t n, int32_t Hd,
+                               void* out, usdm_stream_t stream) {
+  USDM_CHECK_ARG(table && out && (ids || next_token) && n > 0 && Hd % 8 == 0, "usdm_embed_rows: bad args");
+  hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table, ids, next_token, n, Hd,
+                     (bf16_t*)out);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_rope_cache(const usdm_rope_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->qkv && pa->cos && pa->sin && pa->kcache && pa->vcache, "usdm_rope_cache: null args");
+  const usdm_rope_args& a = *pa;
+  USDM_CHECK_ARG(a.S > 0 && a.pos0 >= 0 && a.pos0 + a.S <= a.ctx_max && a.pos0 + a.S <= a.max_pos, "usdm_rope_cache: positions exceed the cache / rope table");
+  USDM_CHECK_ARG(!a.vt || a.vt_ld >= a.S, "usdm_rope_cache: vt_ld");
+  hipLaunchKernelGGL(rope_cache_kernel, dim3(a.S, a.Hq + 2 * a.Hkv), dim3(64), 0, (hipStream_t)stream, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t stream) {
+  USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && pa->pm && pa->pl && pa->po && pa->out, "usdm_attn_decode: null args");
+  const usdm_attn_decode_args& a = *pa;
+  USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0, "usdm_attn_decode: heads");
+  USDM_CHECK_ARG(cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
+  const int G = a.Hq / a.Hkv;
+  dim3 grid(a.Hkv, a.NS);
+  hipStream_t st = (hipStream_t)stream;
+  if (G == 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, st, a);
+  else if (G == 2) hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);
+  else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
+  USDM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_residual_add(void* h, const float* delta, int32_t n, usdm_stream_t stream) {
+  USDM_CHECK_ARG(h && delta && n > 0, "usdm_residual_add: bad args");
+  hipLaunchKernelGGL(residual_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)h, delta, n);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int usdm_sizeof_gemv_args(void) { return (int)sizeof(usdm_gemv_args); }
+extern "C" int usdm_sizeof_decode_state(void) { return (int)sizeof(usdm_decode_state); }
+extern "C" int usdm_sizeof_rope_args(void) { return (int)sizeof(usdm_rope_args); }
+extern "C" int usdm_sizeof_attn_decode_args(void) { return (int)sizeof(usdm_attn_decode_args); }

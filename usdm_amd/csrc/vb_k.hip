@@ -106,3 +106,40 @@ extern "C" int usdm_copy_bytes(void* dst, const void* src, int64_t nbytes, usdm_
 }
 extern "C" int usdm_sizeof_vb_input_args(void) { return (int)sizeof(usdm_vb_input_args); }
 extern "C" int usdm_sizeof_vb_solver_args(void) { return (int)sizeof(usdm_vb_solver_args); }
+
+// ---------------------------------------------------------------------------------------------
+// process_unit (model_util.py:50-54): repeat_interleave(rep) -> frames of `hop` -> per-frame mode,
+// ties -> smallest id.  Integer work, one thread per output frame, nothing materialised.
+namespace {
+__global__ void process_unit_kernel(const int64_t* __restrict__ u, int n, int rep, int hop, int64_t* __restrict__ out,
+                                    int nframes) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  const int64_t lo = (int64_t)f * hop, hi = lo + hop;  // [lo, hi) in the repeated sequence
+  const int i0 = (int)(lo / rep), i1 = (int)((hi - 1) / rep);
+  int64_t best_v = 0;
+  int64_t best_c = -1;
+  for (int i = i0; i <= i1; ++i) {
+    const int64_t v = u[i];
+    int64_t c = 0;
+    for (int j = i0; j <= i1; ++j) {
+      if (u[j] != v) continue;
+      const int64_t a = max((int64_t)j * rep, lo), b = min((int64_t)(j + 1) * rep, hi);
+      c += b - a;
+    }
+    if (c > best_c || (c == best_c && v < best_v)) { best_c = c; best_v = v; }
+  }
+  out[f] = best_v;
+}
+}  // namespace
+
+extern "C" int usdm_process_unit(const int64_t* units, int32_t n, int32_t rep, int32_t hop, int64_t* out,
+                                 int32_t nframes, usdm_stream_t stream) {
+  USDM_CHECK_ARG(units && out && n > 0 && rep > 0 && hop > 0, "usdm_process_unit: bad args");
+  USDM_CHECK_ARG(nframes == (int)(((int64_t)n * rep) / hop), "usdm_process_unit: nframes must be floor(n*rep/hop)");
+  if (nframes == 0) return 0;
+  hipLaunchKernelGGL(process_unit_kernel, dim3(cdiv(nframes, 128)), dim3(128), 0, (hipStream_t)stream, units, n, rep, hop,
+                     out, nframes);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}

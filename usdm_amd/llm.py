@@ -1,0 +1,329 @@
+"""Mistral-7B speech-text LLM on MI355X: drop-in for the object the reference obtains from
+`AutoModelForCausalLM.from_pretrained('naver-ai/USDM-DailyTalk', torch_dtype=bf16)` (src/inference.py:116-124)
+as far as the hot path uses it: `.generate(input_ids=[1,L], max_length, do_sample, bad_words_ids, top_p, top_k,
+temperature, eos_token_id) -> LongTensor[1,L']` (src/inference.py:63-83).
+
+Host side: Python plans of C-ABI launches (libusdm_hip.so).
+  prefill : usdm_embed_rows, usdm_norm(rms), usdm_gemm (MFMA bf16; SwiGLU / residual epilogues), usdm_rope_cache,
+            usdm_attention(mode 1, causal GQA)                                   — one eager plan per prompt length
+  decode  : usdm_gemv x4 per layer (RMSNorm, residual add, SwiGLU fused), usdm_attn_decode, lm_head GEMV with
+            ban-mask + arg-max, all state on the device -> ONE hipGraph replayed per token
+  TP > 1  : Megatron-style shards (q/k/v heads, MLP columns, vocab rows); o_proj/down_proj produce f32 partial
+            sums that are all-reduced over RCCL (torch.distributed 'nccl'), lm_head arg-max partials all-gathered.
+Weights: HF state-dict key names (model.layers.N.self_attn.q_proj.weight, ...), bf16.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import ACT_SWIGLU
+from .graph import GraphedPlan
+
+MISTRAL_7B_USDM = dict(vocab_size=42003, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                       num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5,
+                       rope_theta=10000.0, max_position_embeddings=32768)
+
+
+def _pack_gate_up(gate, up):
+    """[I,K] gate and up -> [2I,K] in blocks of 32 rows = 16 gate + 16 up (SwiGLU epilogue layout)."""
+    I, K = gate.shape
+    return torch.stack([gate.reshape(I // 16, 16, K), up.reshape(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous()
+
+
+class USDMForCausalLM:
+    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=16):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("USDMForCausalLM (usdm_amd) runs on the MI355X only; there is no CPU fallback")
+        c = self.cfg
+        if c["head_dim"] != 128:
+            raise NotImplementedError("decode/prefill attention kernels are built for head_dim 128 (Mistral-7B)")
+        self.tp_rank, self.tp_size, self.group = tp_rank, tp_size, group
+        self.Hq, self.Hkv = c["num_attention_heads"] // tp_size, c["num_key_value_heads"] // tp_size
+        if self.Hq * tp_size != c["num_attention_heads"] or self.Hkv * tp_size != c["num_key_value_heads"] or self.Hkv < 1:
+            raise ValueError("tp_size must divide both head counts")
+        self.I = c["intermediate_size"] // tp_size
+        if self.I * tp_size != c["intermediate_size"] or self.I % 16:
+            raise ValueError("intermediate_size / tp_size must be a multiple of 16")
+        V = c["vocab_size"]
+        self.Vloc = (V + tp_size - 1) // tp_size
+        self.v0 = min(V, tp_rank * self.Vloc)
+        self.v1 = min(V, self.v0 + self.Vloc)
+        self.ctx_max = (ctx_max + 63) // 64 * 64
+        self.NS = decode_splits
+        self.W = None
+        self._prefill_plans = {}
+        self._decode = None
+        self._ban_cache = {}
+        self.stats = {}
+        self.keep_logits = False  # debug/tests: keep the fp32 (bf16-valued) logits of the last step
+        self.last_logits = None
+
+    # ------------------------------------------------------------------ weights
+    def _shard(self, sd_get):
+        """Build this rank's packed weights from a getter name -> bf16 tensor (any device)."""
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        d, r = c["head_dim"], self.tp_rank
+        g = lambda n: sd_get(n).to(dev, bf)
+        W = {"embed": g("model.embed_tokens.weight").contiguous(),
+             "norm": sd_get("model.norm.weight").to(dev, torch.float32).contiguous(),
+             "lm_head": g("lm_head.weight")[self.v0:self.v1].contiguous(), "layers": []}
+        for l in range(c["num_hidden_layers"]):
+            p = f"model.layers.{l}."
+            q = g(p + "self_attn.q_proj.weight")[r * self.Hq * d:(r + 1) * self.Hq * d]
+            k = g(p + "self_attn.k_proj.weight")[r * self.Hkv * d:(r + 1) * self.Hkv * d]
+            v = g(p + "self_attn.v_proj.weight")[r * self.Hkv * d:(r + 1) * self.Hkv * d]
+            o = g(p + "self_attn.o_proj.weight")[:, r * self.Hq * d:(r + 1) * self.Hq * d]
+            ga = g(p + "mlp.gate_proj.weight")[r * self.I:(r + 1) * self.I]
+            up = g(p + "mlp.up_proj.weight")[r * self.I:(r + 1) * self.I]
+            dn = g(p + "mlp.down_proj.weight")[:, r * self.I:(r + 1) * self.I]
+            W["layers"].append(dict(
+                qkv=torch.cat([q, k, v], 0).contiguous(), o=o.contiguous(), gu=_pack_gate_up(ga, up), down=dn.contiguous(),
+                ln1=sd_get(p + "input_layernorm.weight").to(dev, torch.float32).contiguous(),
+                ln2=sd_get(p + "post_attention_layernorm.weight").to(dev, torch.float32).contiguous()))
+        return W
+
+    @classmethod
+    def from_state_dict(cls, sd, cfg, device, **kw):
+        m = cls(cfg, device, **kw)
+        m.W = m._shard(lambda n: sd[n])
+        m._alloc()
+        return m
+
+    @classmethod
+    def random_init(cls, cfg, device, seed=0, **kw):
+        """Random weights generated shard-by-shard ON the device (synthetic benchmark weights;
+        values differ from oracle.mistral_oracle.random_state_dict, which is CPU-generated)."""
+        m = cls(cfg, device, **kw)
+        c, d = m.cfg, m.cfg["head_dim"]
+        H, I, V = c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+        gen = torch.Generator(device=m.device).manual_seed(seed)
+        shapes = {"model.embed_tokens.weight": ((V, H), 1.0), "lm_head.weight": ((V, H), H ** -0.5)}
+        for l in range(c["num_hidden_layers"]):
+            p = f"model.layers.{l}."
+            shapes.update({p + "self_attn.q_proj.weight": ((c["num_attention_heads"] * d, H), H ** -0.5),
+                           p + "self_attn.k_proj.weight": ((c["num_key_value_heads"] * d, H), H ** -0.5),
+                           p + "self_attn.v_proj.weight": ((c["num_key_value_heads"] * d, H), H ** -0.5),
+                           p + "self_attn.o_proj.weight": ((H, c["num_attention_heads"] * d), H ** -0.5),
+                           p + "mlp.gate_proj.weight": ((I, H), H ** -0.5), p + "mlp.up_proj.weight": ((I, H), H ** -0.5),
+                           p + "mlp.down_proj.weight": ((H, I), I ** -0.5)})
+
+        def get(n):
+            if n.endswith("norm.weight") or n.endswith("layernorm.weight"):
+                return torch.ones(H, device=m.device)
+            shape, sc = shapes[n]
+            return (torch.randn(shape, device=m.device, dtype=torch.float32, generator=gen) * sc).to(torch.bfloat16)
+        m.W = m._shard(get)
+        m._alloc()
+        return m
+
+    def weight_bytes_per_token(self):
+        """bf16 bytes a decode step must stream on this rank (layers + lm_head shard)."""
+        n = sum(l[k].numel() for l in self.W["layers"] for k in ("qkv", "o", "gu", "down")) + self.W["lm_head"].numel()
+        return 2 * n
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        c, dev = self.cfg, self.device
+        L, d = c["num_hidden_layers"], c["head_dim"]
+        bf = torch.bfloat16
+        self.kcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
+        self.vcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
+        # rope tables exactly as HF MistralRotaryEmbedding computes them (fp32 on the host, cast to bf16)
+        inv_freq = 1.0 / (c["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+        fr = torch.arange(self.ctx_max).float()[:, None] * inv_freq[None, :]
+        self.cos = fr.cos().to(bf).to(dev).contiguous()
+        self.sin = fr.sin().to(bf).to(dev).contiguous()
+        i32 = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=dev)
+        self.max_out = self.ctx_max
+        self.st_next, self.st_step, self.st_pos = i32(1), i32(1), i32(1)
+        self.st_out = i32(self.max_out)
+        self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
+        self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
+        self.nparts = ops.gemv_nblocks(self.v1 - self.v0)
+        self.part_val = torch.zeros(self.nparts * self.tp_size, dtype=torch.float32, device=dev)
+        self.part_idx = torch.zeros(self.nparts * self.tp_size, dtype=torch.int32, device=dev)
+        self.part_val_loc = torch.zeros(self.nparts, dtype=torch.float32, device=dev) if self.tp_size > 1 else self.part_val
+        self.part_idx_loc = torch.zeros(self.nparts, dtype=torch.int32, device=dev) if self.tp_size > 1 else self.part_idx
+
+    # ------------------------------------------------------------------ collectives (TP only)
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=self.group)
+
+    def _gather_partials(self):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
+        dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
+
+    def _lm_head_and_pick(self, plan, x, advance_pos, segs):
+        c = self.cfg
+        if self.keep_logits and self.last_logits is None:
+            self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
+        ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
+                 y32=self.last_logits if self.keep_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0, plan=plan)
+        st = ops.decode_state(self.st_next, self.st_out, self.st_step, self.st_pos, advance_pos=advance_pos)
+        if self.tp_size > 1:
+            segs.append(plan)
+            segs.append(self._gather_partials)
+            plan = ops.Plan()
+        ops.argmax_final(self.part_val, self.part_idx, self.nparts * self.tp_size, st, plan=plan)
+        plan.hold(st)
+        segs.append(plan)
+
+    # ------------------------------------------------------------------ plans
+    def _build_prefill(self, S):
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
+        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, self.tp_size
+        nq = (Hq + 2 * Hkv) * d
+        Spad = (S + 63) // 64 * 64
+        segs, plan = [], ops.Plan()
+        Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        io = dict(ids=Z(S, dt=torch.int64))
+        h, xn, qkv, ao, act = Z(S, H), Z(S, H), Z(S, nq), Z(S, Hq * d), Z(S, I)
+        vt = Z(Hkv, d, Spad)
+        part = Z(S, H, dt=torch.float32) if tp > 1 else None
+        ops.embed_rows(self.W["embed"], h, Hd=H, ids=io["ids"], n=S, plan=plan)
+        for l in range(L):
+            w = self.W["layers"][l]
+            ops.norm(h, w["ln1"], None, rows=S, C=H, eps=c["rms_norm_eps"], rms=True, round_bf16=True, out16=xn, plan=plan)
+            ops.gemm(xn, w["qkv"], M=S, N=nq, Kc=H, out16=qkv, plan=plan)
+            ops.rope_cache(qkv, self.cos, self.sin, self.kcache[l], self.vcache[l], ld=nq, S=S, pos0=0, Hq=Hq, Hkv=Hkv,
+                           ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=vt, vt_ld=Spad, plan=plan)
+            ops.attention(qkv, self.kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
+                          q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d), v_strides=(0, d * Spad, Spad),
+                          o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
+            if tp == 1:
+                ops.gemm(ao, w["o"], M=S, N=H, Kc=Hq * d, residual=h, ldr=H, round_bf16=True, out16=h, plan=plan)
+            else:
+                ops.gemm(ao, w["o"], M=S, N=H, Kc=Hq * d, out32=part, plan=plan)
+                segs += [plan, (lambda t=part: self._all_reduce(t))]
+                plan = ops.Plan()
+                ops.residual_add(h, part, S * H, plan=plan)
+            ops.norm(h, w["ln2"], None, rows=S, C=H, eps=c["rms_norm_eps"], rms=True, round_bf16=True, out16=xn, plan=plan)
+            ops.gemm(xn, w["gu"], M=S, N=2 * I, Kc=H, act=ACT_SWIGLU, round_bf16=True, out16=act, ldc=I, plan=plan)
+            if tp == 1:
+                ops.gemm(act, w["down"], M=S, N=H, Kc=I, residual=h, ldr=H, round_bf16=True, out16=h, plan=plan)
+            else:
+                ops.gemm(act, w["down"], M=S, N=H, Kc=I, out32=part, plan=plan)
+                segs += [plan, (lambda t=part: self._all_reduce(t))]
+                plan = ops.Plan()
+                ops.residual_add(h, part, S * H, plan=plan)
+        self._lm_head_and_pick(plan, h[S - 1], False, segs)
+        segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
+        return segs, io
+
+    def _build_decode(self):
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
+        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, self.tp_size
+        nq = (Hq + 2 * Hkv) * d
+        segs, plan = [], ops.Plan()
+        Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        h, qkv, ao, act = Z(H), Z(nq), Z(Hq * d), Z(I)
+        pm, pl, po = Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS * d, dt=torch.float32)
+        part = Z(H, dt=torch.float32) if tp > 1 else None
+        ops.embed_rows(self.W["embed"], h, Hd=H, next_token=self.st_next, n=1, plan=plan)
+        for l in range(L):
+            w = self.W["layers"][l]
+            ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
+            ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, plan=plan)
+            if tp == 1:
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, plan=plan)
+            else:
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, plan=plan)
+                segs += [plan, (lambda t=part: self._all_reduce(t))]
+                plan = ops.Plan()
+                ops.residual_add(h, part, H, plan=plan)
+            ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, plan=plan)
+            if tp == 1:
+                ops.gemv(w["down"], act, N=H, K=I, residual=h, y16=h, plan=plan)
+            else:
+                ops.gemv(w["down"], act, N=H, K=I, round_bf16=False, y32=part, plan=plan)
+                segs += [plan, (lambda t=part: self._all_reduce(t))]
+                plan = ops.Plan()
+                ops.residual_add(h, part, H, plan=plan)
+        self._lm_head_and_pick(plan, h, True, segs)
+        segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
+        return segs
+
+    @staticmethod
+    def _run_segs(segs):
+        for s in segs:
+            if isinstance(s, ops.Plan):
+                s.run()
+            else:
+                s()
+
+    # ------------------------------------------------------------------ generate
+    def _ban_mask(self, bad_words_ids):
+        if not bad_words_ids:
+            return self.ban_all_off
+        key = id(bad_words_ids)
+        hit = self._ban_cache.get(key)
+        if hit is not None and hit[0] is bad_words_ids:
+            return hit[1]
+        m = torch.zeros(self.cfg["vocab_size"], dtype=torch.uint8)
+        for w in bad_words_ids:
+            if len(w) != 1:
+                raise NotImplementedError("multi-token bad words are not used by the reference path (inference.py:41-45)")
+            m[w[0]] = 1
+        t = m[self.v0:self.v1].to(self.device).contiguous()
+        self._ban_cache[key] = (bad_words_ids, t)
+        return t
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, max_length=None, do_sample=False, bad_words_ids=None, top_p=1.0, top_k=None,
+                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, **unused):
+        """Greedy generation with the call shape of src/inference.py:63-83.  do_sample=True is accepted only
+        with top_k == 1 (what the reference passes): that is arg-max of the ban-masked logits."""
+        if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise ValueError("input_ids must be a LongTensor of shape [1, L] (batch 1, as the reference calls it)")
+        if do_sample and top_k != 1:
+            raise NotImplementedError("sampling other than top_k=1 (== greedy) is outside the reference's inference path")
+        if temperature != 1.0 or top_p != 1.0:
+            raise NotImplementedError("temperature/top_p other than 1.0 are outside the reference's inference path")
+        L0 = input_ids.shape[1]
+        if max_new_tokens is None:
+            if max_length is None:
+                raise ValueError("max_length or max_new_tokens is required")
+            max_new_tokens = max_length - L0
+        max_new_tokens = min(max_new_tokens, self.ctx_max - L0, self.max_out)
+        if max_new_tokens <= 0:
+            return input_ids.clone()
+        if L0 not in self._prefill_plans:
+            self._prefill_plans[L0] = self._build_prefill(L0)
+        segs, io = self._prefill_plans[L0]
+        io["ids"].copy_(input_ids[0])
+        self.ban.copy_(self._ban_mask(bad_words_ids))
+        self.st_pos.fill_(L0)
+        self.st_step.zero_()
+        self._run_segs(segs)  # prefill + first token
+        if self._decode is None:
+            dsegs = self._build_decode()
+            self._decode = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else dsegs
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
+        produced, done, chunk = 1, False, 8
+        toks = []
+        while True:
+            toks = self.st_out[:produced].tolist()  # host sync point (EOS check)
+            hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
+            if hit:
+                toks = toks[:hit[0] + 1]
+                break
+            if produced >= max_new_tokens:
+                toks = toks[:max_new_tokens]
+                break
+            n = min(chunk, max_new_tokens - produced)
+            for _ in range(n):
+                if isinstance(self._decode, GraphedPlan):
+                    self._decode.run()
+                else:
+                    self._run_segs(self._decode)
+            produced += n
+        out = torch.cat([input_ids[0], torch.tensor(toks, dtype=torch.long, device=input_ids.device)])
+        return out.unsqueeze(0)

@@ -8,7 +8,8 @@ import ctypes as C_
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, AttnArgs, GemmArgs, NormArgs, SnakeArgs, VbInputArgs, VbSolverArgs, check, lib
+from ._lib import (BF16, F32, AttnArgs, AttnDecodeArgs, DecodeState, GemmArgs, GemvArgs, NormArgs, RopeArgs, SnakeArgs,
+                   VbInputArgs, VbSolverArgs, check, lib)
 
 
 def _stream():
@@ -188,3 +189,74 @@ def vb_solver_step(vout, z, *, B, F, S, mode, dt, cfg=False, gs=0.0, v1=None, ep
 def copy_bytes(dst, src, nbytes, plan=None):
     _need_cuda(dst, src)
     _go(plan, "usdm_copy_bytes", lib.usdm_copy_bytes, _ptr(dst), _ptr(src), C_.c_int64(nbytes))
+
+
+def process_unit(units, rep, hop):
+    """usdm_process_unit: int64 [n] on the GPU -> int64 [floor(n*rep/hop)]."""
+    _need_cuda(units)
+    if units.dtype != torch.int64 or units.dim() != 1:
+        raise TypeError("units must be a 1-D int64 tensor")
+    n = units.numel()
+    nframes = (n * rep) // hop
+    out = torch.empty(nframes, dtype=torch.int64, device=units.device)
+    if n == 0 or nframes == 0:
+        return out
+    check(lib.usdm_process_unit(_ptr(units.contiguous()), C_.c_int32(n), C_.c_int32(rep), C_.c_int32(hop), _ptr(out),
+                                C_.c_int32(nframes), _stream()), "usdm_process_unit")
+    return out
+
+
+def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
+         ban=None, part_val=None, part_idx=None, idx_offset=0, plan=None):
+    """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h)."""
+    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx)
+    a = GemvArgs()
+    a.W, a.ldw, a.N, a.K = _ptr(W), (ldw if ldw is not None else K), N, K
+    a.x, a.norm_w, a.eps = _ptr(x), _ptr(norm_w), eps
+    a.act, a.round_bf16 = act, int(round_bf16)
+    a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
+    a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
+    _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
+
+
+def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True):
+    st = DecodeState()
+    st.next_token, st.out_tokens, st.step, st.pos = _ptr(next_token), _ptr(out_tokens), _ptr(step), _ptr(pos)
+    st.max_out, st.id_offset, st.advance_pos = out_tokens.numel(), id_offset, int(advance_pos)
+    return st
+
+
+def argmax_final(part_val, part_idx, nparts, st, plan=None):
+    _need_cuda(part_val, part_idx)
+    _go(plan, "usdm_argmax_final", lib.usdm_argmax_final, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st))
+
+
+def embed_rows(table, out, *, Hd, ids=None, next_token=None, n=1, plan=None):
+    _need_cuda(table, out, ids, next_token)
+    _go(plan, "usdm_embed_rows", lib.usdm_embed_rows, _ptr(table), _ptr(ids), _ptr(next_token), C_.c_int32(n), C_.c_int32(Hd), _ptr(out))
+
+
+def rope_cache(qkv, cos, sin, kcache, vcache, *, ld, S, pos0, Hq, Hkv, ctx_max, max_pos, vt=None, vt_ld=0, plan=None):
+    _need_cuda(qkv, cos, sin, kcache, vcache, vt)
+    a = RopeArgs()
+    a.qkv, a.ld, a.S, a.pos0, a.Hq, a.Hkv, a.ctx_max, a.max_pos = _ptr(qkv), ld, S, pos0, Hq, Hkv, ctx_max, max_pos
+    a.cos, a.sin, a.kcache, a.vcache, a.vt, a.vt_ld = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache), _ptr(vt), vt_ld
+    _go(plan, "usdm_rope_cache", lib.usdm_rope_cache, C_.byref(a))
+
+
+def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, plan=None):
+    _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out)
+    a = AttnDecodeArgs()
+    a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
+    a.cos, a.sin, a.kcache, a.vcache = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache)
+    a.pm, a.pl, a.po, a.out = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out)
+    _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
+
+
+def residual_add(h, delta, n, plan=None):
+    _need_cuda(h, delta)
+    _go(plan, "usdm_residual_add", lib.usdm_residual_add, _ptr(h), _ptr(delta), C_.c_int32(n))
+
+
+def gemv_nblocks(N, act=0):
+    return lib.usdm_gemv_nblocks(C_.c_int32(N), C_.c_int32(act))

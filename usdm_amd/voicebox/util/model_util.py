@@ -1,0 +1,74 @@
+"""Decoder orchestration drop-in (reference: src/decoder/voicebox/util/model_util.py:18-105).
+
+Same names and signatures: mel_mean, mel_std, process_unit, initialize_decoder, reconstruct_speech.
+Differences forced by the environment (no network, no librosa/torchaudio):
+  * initialize_decoder loads from local directories under model_cache_dir
+    (<dir>/xlsr-token-Voicebox, <dir>/bigvgan_22khz_80band) instead of hub names;
+  * the reference-prompt mel front end (get_mel, model_util.py:24-38) is SURVEY.md §8(f) "next":
+    reconstruct_speech accepts `reference_mel=` / `reference_unit=` tensors instead of decoding a file.
+"""
+import os
+
+import torch
+
+from ... import ops
+from ..model import Voicebox
+from ..vocoder.models import BigVGAN
+
+mel_mean = -5.5419
+mel_std = 2.1575
+
+
+def get_mel(filepath, length=None, hps=None):
+    raise NotImplementedError("get_mel (torchaudio load + Resample + mel_spectrogram, model_util.py:24-38) is the "
+                              "'next' row of SURVEY.md §8(f); pass reference_mel= to reconstruct_speech")
+
+
+def process_unit(unit, hps, device):
+    """50 Hz unit ids -> one id per mel frame (mode over each hop), on the GPU (model_util.py:50-54)."""
+    unit = unit.to(device)
+    rep = hps.sampling_rate // 50
+    out = ops.process_unit(unit, rep, hps.hop_size)
+    new_length = (unit.numel() * rep) // hps.hop_size * hps.hop_size
+    return out.unsqueeze(0), new_length
+
+
+def initialize_decoder(model_cache_dir, device):
+    voicebox = Voicebox.from_pretrained(os.path.join(model_cache_dir, "xlsr-token-Voicebox")).to(device).eval()
+    vocoder = BigVGAN.from_pretrained(os.path.join(model_cache_dir, "bigvgan_22khz_80band")).to(device).eval()
+    vocoder.remove_weight_norm()
+    return voicebox, vocoder
+
+
+@torch.inference_mode()
+def reconstruct_speech(agent_unit, device, reference_path, token_extractor, voicebox, vocoder, n_timesteps=50,
+                       reference_mel=None, reference_unit=None, noise=None):
+    """units -> waveform float32 numpy [256 * frames] (model_util.py:72-105).
+
+    With a speech prompt, supply `reference_unit` (50 Hz ids of the prompt, e.g. from
+    token_extractor.predict) and `reference_mel` ([1, 80, frames] log-mel, un-normalised)."""
+    agent_unit, _ = process_unit(agent_unit, vocoder.h, device)
+    if reference_path is not None and reference_mel is None:
+        raise NotImplementedError("decoding reference_path needs get_mel (SURVEY.md §8f 'next'); pass reference_mel/reference_unit")
+    if reference_mel is not None:
+        if reference_unit is None:
+            raise ValueError("reference_unit (50 Hz ids of the prompt) is required with reference_mel")
+        reference_unit, new_length = process_unit(reference_unit, vocoder.h, device)
+        P = reference_unit.shape[-1]
+        reference_mel = (reference_mel.to(device).float()[:, :, :P] - mel_mean) / mel_std
+        dummy_y = torch.zeros(agent_unit.shape[0], vocoder.h.num_mels, P + agent_unit.shape[-1], device=device)
+        dummy_y[:, :, :P] = reference_mel
+        dummy_y_lengths = torch.LongTensor([dummy_y.shape[-1]]).to(device)
+        prompt_lengths = torch.LongTensor([P]).to(device)
+        unit = torch.cat([reference_unit, agent_unit], dim=-1)
+        y_dec = voicebox.generate(unit, dummy_y, dummy_y_lengths, n_timesteps=n_timesteps, solver="heun", gradient_scale=1.0,
+                                  speech_prompt=True, prompt_lengths=prompt_lengths, noise=noise)
+        y_dec = y_dec[:, :, P:]
+    else:
+        dummy_y = torch.zeros(agent_unit.shape[0], vocoder.h.num_mels, agent_unit.shape[-1], device=device)
+        dummy_y_lengths = torch.LongTensor([dummy_y.shape[-1]]).to(device)
+        y_dec = voicebox.generate(agent_unit, dummy_y, dummy_y_lengths, n_timesteps=n_timesteps, solver="heun",
+                                  gradient_scale=1.0, speech_prompt=False, noise=noise)
+    # inverse normalisation is folded into the vocoder's layout kernel (y*std + mean, model_util.py:103)
+    audio_dec = vocoder.forward(y_dec.contiguous(), mel_std, mel_mean).cpu().squeeze().clamp(-1, 1).numpy()
+    return audio_dec
