@@ -261,6 +261,22 @@ int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 /* h = bf16(h + bf16(delta)) : residual add after a tensor-parallel all-reduce of f32 partial sums */
 int usdm_residual_add(void* h_bf16, const float* delta, int32_t n, usdm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * XLS-R / k-means unit extractor (third-party seamless_communication UnitExtractor.predict, call sites
+ * src/inference.py:59,111-113, util/model_util.py:79-80).  fp32 throughout; GEMMs are usdm_gemm(F32).
+ * ---------------------------------------------------------------------------------------------- */
+/* y = layer_norm(x) over all n samples (F.layer_norm(wave, wave.shape)) */
+int usdm_wave_layernorm(const float* x, int32_t n, float eps, float* y, usdm_stream_t stream);
+/* first conv layer fused: Conv1d(1->512,k=10,stride) + LayerNorm(512) + GELU -> channels-last [T][512] */
+int usdm_w2v_conv0(const float* x, int32_t n, int32_t T, int32_t C, int32_t k, int32_t stride, const float* w,
+                   const float* b, const float* ln_g, const float* ln_b, float eps, float* out, usdm_stream_t stream);
+/* in-place softmax of x[row][seg*ldseg + 0..n), pad columns [n,npad) zeroed (attention probabilities) */
+int usdm_softmax_segments(float* x, int32_t rows, int32_t nseg, int32_t n, int32_t npad, int64_t ldrow, int32_t ldseg,
+                          usdm_stream_t stream);
+/* ids[t] = argmin_n(|x_t|^2 - 2*dots[t][n] + csq[n]) (first minimum); margin[t] = runner-up - best (optional) */
+int usdm_kmeans_argmin(const float* x, int32_t T, int32_t D, const float* dots, int64_t ldd, const float* csq,
+                       int32_t n_units, int64_t* ids, float* margin, usdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,3 +108,40 @@ def test_mistral_oracle_vs_installed_transformers():
                         bad_words_ids=bad, eos_token_id=299, pad_token_id=0)
     mine = MO.greedy_generate(sd, cfg, ids[0], 12, bad_words_ids=bad, eos_token_id=299)
     assert hf[0].tolist() == mine
+
+
+def test_w2v_oracle_vs_hf_wav2vec2_and_kmeans():
+    """Structural pin of the XLS-R restatement against HF Wav2Vec2Model (independent implementation of the
+    same architecture); the seamless_communication tokenizer itself is absent -> 'parity unpinned'."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    from oracle import w2v_oracle as WO
+    cfg = dict(WO.XLSR_1B, conv_dim=(32,) * 7, hidden_size=64, num_attention_heads=4, intermediate_size=128,
+               num_hidden_layers=3, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, n_units=50)
+    hf = transformers.Wav2Vec2Config(
+        hidden_size=64, num_hidden_layers=3, num_attention_heads=4, intermediate_size=128, conv_dim=cfg["conv_dim"],
+        conv_kernel=cfg["conv_kernel"], conv_stride=cfg["conv_stride"], feat_extract_norm="layer", conv_bias=True,
+        do_stable_layer_norm=True, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, hidden_dropout=0.0,
+        attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0,
+        attn_implementation="eager")
+    m = transformers.Wav2Vec2Model(hf).eval()
+    sd = WO.random_state_dict(cfg, seed=4)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k in ("masked_spec_embed", "encoder.layer_norm.weight", "encoder.layer_norm.bias") for k in res.missing_keys), res.missing_keys
+    wave = torch.randn(4000, generator=torch.Generator().manual_seed(5)) * 0.1
+    normed = torch.nn.functional.layer_norm(wave, wave.shape)
+    with torch.no_grad():
+        hs = m(normed[None], output_hidden_states=True).hidden_states
+    for idx in (0, 1, 2):  # hidden_states[idx+1] is the output of encoder layer idx
+        got = WO.features(sd, cfg, wave, idx)
+        assert got.shape[0] == WO.n_frames(4000, cfg)
+        if idx < 2:
+            _close(got, hs[idx + 1][0], 2e-5)
+    assert WO.n_frames(160000, WO.XLSR_1B) == 499 and WO.n_frames(48000, WO.XLSR_1B) == 149
+    # k-means stage: formula == brute-force fp64 nearest centroid
+    x = torch.randn(40, 64, generator=torch.Generator().manual_seed(6))
+    C = torch.randn(50, 64, generator=torch.Generator().manual_seed(7))
+    ids, _ = WO.kmeans_assign(x, C)
+    brute = ((x.double()[:, None] - C.double()[None]) ** 2).sum(-1).argmin(-1)
+    assert torch.equal(ids, brute)

@@ -260,3 +260,26 @@ def residual_add(h, delta, n, plan=None):
 
 def gemv_nblocks(N, act=0):
     return lib.usdm_gemv_nblocks(C_.c_int32(N), C_.c_int32(act))
+
+
+def wave_layernorm(x, y, n, eps=1e-5, plan=None):
+    _need_cuda(x, y)
+    _go(plan, "usdm_wave_layernorm", lib.usdm_wave_layernorm, _ptr(x), C_.c_int32(n), C_.c_float(eps), _ptr(y))
+
+
+def w2v_conv0(x, w, b, g, be, out, *, n, T, C, k, stride, eps=1e-5, plan=None):
+    _need_cuda(x, w, b, g, be, out)
+    _go(plan, "usdm_w2v_conv0", lib.usdm_w2v_conv0, _ptr(x), C_.c_int32(n), C_.c_int32(T), C_.c_int32(C), C_.c_int32(k),
+        C_.c_int32(stride), _ptr(w), _ptr(b), _ptr(g), _ptr(be), C_.c_float(eps), _ptr(out))
+
+
+def softmax_segments(x, *, rows, nseg, n, npad, ldrow, ldseg, plan=None):
+    _need_cuda(x)
+    _go(plan, "usdm_softmax_segments", lib.usdm_softmax_segments, _ptr(x), C_.c_int32(rows), C_.c_int32(nseg), C_.c_int32(n),
+        C_.c_int32(npad), C_.c_int64(ldrow), C_.c_int32(ldseg))
+
+
+def kmeans_argmin(x, dots, csq, ids, *, T, D, n_units, ldd, margin=None, plan=None):
+    _need_cuda(x, dots, csq, ids, margin)
+    _go(plan, "usdm_kmeans_argmin", lib.usdm_kmeans_argmin, _ptr(x), C_.c_int32(T), C_.c_int32(D), _ptr(dots), C_.c_int64(ldd),
+        _ptr(csq), C_.c_int32(n_units), _ptr(ids), _ptr(margin))
