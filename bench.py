@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Headline benchmark: end-to-end real-time factor + LLM tokens/s of the USDM inference hot path on MI355X.
+
+One "step" = one synthetic 10 s utterance through the whole path with inputs resident in HBM:
+  16 kHz wave (160 000 samples) -> XLS-R/k-means units (499) -> 7B LLM, three greedy rounds as src/inference.py:61-83
+  (unit->text 32 tok, text->text 32 tok, text->unit 500 tok; EOS disabled so the step count is fixed) ->
+  process_unit (500 -> 861 frames) -> Token-Voicebox, 64 "timesteps" Heun = 63 NFE with CFG and a 3 s speech
+  prompt -> BigVGAN -> 220 416 samples of 22.05 kHz audio (9.996 s).
+Random-init weights of the exact architectures (no network), synthetic data.
+N > 1: the LLM runs tensor-parallel over N ranks (RCCL all-reduce); tokenizer / Voicebox / vocoder are replicated
+(they do not shard within one utterance) -> strong scaling of ONE utterance; value = RTF of the whole job.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     : the dominant kernel (decode GEMV, HBM-bound) measured live with HIP events
+  cpu_baseline : the CPU oracle timed on the host cores over a bounded sample, extrapolated (stated in "sample")
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "end-to-end real-time factor + LLM tokens/sec, 10 s utterance, 7B TP=1/8"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--units", type=int, default=500, help="generated unit tokens (50 Hz) in the TTS round")
+    ap.add_argument("--text-tokens", type=int, default=32)
+    ap.add_argument("--nt", type=int, default=64, help="Voicebox n_timesteps (Heun halves it)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vocoder-dtype", default="f32", choices=["f32", "bf16"])
+    return ap.parse_args()
+
+
+class Pipeline:
+    def __init__(self, dev, rank, world, group, args):
+        from usdm_amd import synth
+        from usdm_amd.voicebox.util import model_util
+        self.mu = model_util
+        self.dev, self.rank, self.world, self.args = dev, rank, world, args
+        t0 = time.time()
+        self.ue = synth.make_unit_extractor(dev)
+        self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group)
+        self.vb = synth.make_voicebox(dev)
+        self.voc = synth.make_bigvgan(dev, compute_dtype=torch.float32 if args.vocoder_dtype == "f32" else torch.bfloat16)
+        torch.cuda.synchronize()
+        self.build_s = time.time() - t0
+        g = torch.Generator().manual_seed(1)
+        t = torch.arange(160000) / 16000.0
+        wave = sum(torch.sin(2 * torch.pi * f * t + p) for f, p in zip((110, 220, 450, 900, 1800, 3100, 4700, 6100), torch.rand(8, generator=g) * 6.28))
+        self.wave = (0.05 * wave + 0.02 * torch.randn(160000, generator=g)).float().to(dev)
+        self.template_ids = torch.randint(3, 32000, (48,), generator=g)   # stand-in for the tokenised template text
+        self.sep_ids = torch.randint(3, 32000, (6,), generator=g)         # "\n### Agent\n"
+        self.ref_units = torch.randint(0, 10000, (149,), generator=g).to(dev)  # 3 s prompt
+        self.ref_mel = (torch.randn(1, 80, 256, generator=g) * 2.1575 - 5.5419).to(dev)
+        n_noise = 1 + (2 * ((args.nt + 1) // 2) - 1)
+        self.frames = (args.units * 441) // 256
+        self.noise = torch.randn(n_noise, 1, 80, 256 + self.frames, generator=g).to(dev)  # caller-supplied draws
+        from usdm_amd.inference import generate_bad_words_ids
+        self.bad_u2t = generate_bad_words_ids(32000, 42003)
+        self.bad_t2t = generate_bad_words_ids(32002, 42003)
+        self.bad_t2u = generate_bad_words_ids(0, 32002, exclude=[28705])
+        self.ev = {}
+
+    def _mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.setdefault(name, []).append(e)
+
+    def step(self):
+        a, dev = self.args, self.dev
+        self.ev = {}
+        self._mark("t0")
+        units = self.ue.predict(self.wave, 34)                                        # [499]
+        self._mark("tok")
+        unit_tok = units + 32002
+        corr = torch.tensor([32001], device=dev)
+        p1 = torch.cat([self.template_ids.to(dev), unit_tok, corr])[None]
+        o1 = self.llm.generate(input_ids=p1, max_new_tokens=a.text_tokens, do_sample=True, top_k=1, top_p=1.0, temperature=1.0,
+                               bad_words_ids=self.bad_u2t, eos_token_id=None)
+        self._mark("llm1")
+        p2 = torch.cat([o1[0], self.sep_ids.to(dev)])[None]
+        o2 = self.llm.generate(input_ids=p2, max_new_tokens=a.text_tokens, do_sample=True, top_k=1, top_p=1.0, temperature=1.0,
+                               bad_words_ids=self.bad_t2t, eos_token_id=None)
+        self._mark("llm2")
+        p3 = torch.cat([o2[0], corr])[None]
+        o3 = self.llm.generate(input_ids=p3, max_new_tokens=a.units, do_sample=True, top_k=1, top_p=1.0, temperature=1.0,
+                               bad_words_ids=self.bad_t2u, eos_token_id=None)
+        self._mark("llm3")
+        agent_units = (o3[0, p3.shape[1]:] - 32002).clamp_(0, 9999)
+        audio = self.mu.reconstruct_speech(agent_units, dev, None, self.ue, self.vb, self.voc, n_timesteps=a.nt,
+                                           reference_mel=self.ref_mel, reference_unit=self.ref_units, noise=self.noise)
+        self._mark("dec")
+        self.prompt_lens = (p1.shape[1], p2.shape[1], p3.shape[1])
+        self.n_generated = 2 * a.text_tokens + a.units
+        return audio
+
+    def stage_ms(self):
+        torch.cuda.synchronize()
+        g = lambda a, b: self.ev[a][0].elapsed_time(self.ev[b][0])
+        return {"tokenizer": g("t0", "tok"), "llm_asr": g("tok", "llm1"), "llm_t2t": g("llm1", "llm2"), "llm_tts": g("llm2", "llm3"),
+                "voicebox_vocoder": g("llm3", "dec")}
+
+
+def measure_gemv_roofline(llm):
+    """Eager pass over one decode step with a HIP-event pair around every usdm_gemv launch (same stream)."""
+    from usdm_amd import ops
+    segs = llm._build_decode()
+    stream = ops._stream()
+    pairs, nbytes = [], 0
+    for rep in range(3):
+        pairs, nbytes = [], 0
+        for s in segs:
+            if not isinstance(s, ops.Plan):
+                s()
+                continue
+            for what, fn, args in s.calls:
+                if what == "usdm_gemv":
+                    a = args[0]._obj
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn(*args, stream)
+                    e1.record()
+                    pairs.append((e0, e1))
+                    nbytes += 2 * a.N * a.K
+                else:
+                    fn(*args, stream)
+        torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1 in pairs)
+    n = len(pairs)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "gemv_kernel (usdm_gemv, 7B decode weight streaming)", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches_per_token": n, "avg_launch_us": round(ms * 1e3 / n, 2), "avg_bytes_per_launch": int(nbytes / n),
+            "algorithmic_bytes_per_token": int(nbytes)}
+
+
+def cpu_baseline(args):
+    """CPU oracle (kind 'port') on the host cores over a bounded sample; each stage extrapolated as stated."""
+    import math
+    from oracle import bigvgan_oracle as BO, mistral_oracle as MO, voicebox_oracle as VO, w2v_oracle as WO
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    out = {}
+    with torch.no_grad():
+        # BigVGAN: 40 frames full width -> x 861/40
+        h = dict(BO.BIGVGAN_22K_80)
+        sd = BO.random_state_dict(h, 0)
+        mel = torch.randn(1, 80, 40) * 2.1575 - 5.5419
+        t = time.time(); BO.bigvgan_forward(sd, h, mel); out["bigvgan_s"] = (time.time() - t) * 861 / 40
+        del sd
+        # Voicebox: one CFG-doubled NFE at 6 of 24 layers, S=1117 -> x4 layers, x63 NFE
+        cfg = dict(VO.VOICEBOX_CFG, num_hidden_layers=6)
+        sd = VO.random_state_dict(cfg, 0)
+        S = 1117
+        x = torch.randint(0, 10000, (2, S)); y = torch.randn(2, 80, S)
+        t = time.time(); VO.estimator_forward(sd, cfg, x, y, y, torch.full((2, 1, 1), 0.5), torch.tensor([S, S]))
+        out["voicebox_s"] = (time.time() - t) * 4 * (2 * ((args.nt + 1) // 2) - 1)
+        del sd
+        # LLM: 1 of 32 layers at full width, bf16: prefill 128 tokens (-> x prompt tokens/128) and 3 decode steps
+        cfg = dict(MO.MISTRAL_7B_USDM, num_hidden_layers=1, vocab_size=1024)
+        sd = MO.random_state_dict(cfg, 0)
+        ids = torch.randint(0, 1024, (128,))
+        t = time.time(); _, cache = MO.forward(sd, cfg, ids); tp = time.time() - t
+        t = time.time()
+        for _ in range(3):
+            _, cache = MO.forward(sd, cfg, ids[:1], cache)
+        td = (time.time() - t) / 3
+        prompt_tokens = 554 + 592 + 631
+        out["llm_s"] = 32 * (tp * prompt_tokens / 128 + td * (2 * args.text_tokens + args.units))
+        del sd, cache
+        # tokenizer: conv stack on 2 s (-> x5) + 1 encoder layer at 499 frames (-> x35) + k-means on 499 frames
+        cfg = dict(WO.XLSR_1B)
+        sd = WO.random_state_dict(cfg, 0, n_layers=1)
+        t = time.time(); WO.features(sd, cfg, torch.randn(32000) * 0.1, -1); tc = (time.time() - t) * 5
+        xw = torch.randn(160000) * 0.1
+        t = time.time(); f0 = WO.features(sd, cfg, xw, 0); tl = (time.time() - t) - tc
+        cen = torch.randn(10000, 1280)
+        t = time.time(); WO.kmeans_assign(f0, cen); tk = time.time() - t
+        out["tokenizer_s"] = tc + 35 * max(tl, 0.0) + tk
+    total = sum(out.values())
+    return {"value": round(9.996 / total, 5), "unit": "x real-time", "cores": cores, "kind": "port",
+            "stage_seconds_extrapolated": {k: round(v, 2) for k, v in out.items()},
+            "llm_tokens_per_s": round((2 * args.text_tokens + args.units) / out["llm_s"], 3),
+            "sample": "CPU oracle (oracle/*.py, torch CPU, all host cores): BigVGAN 40 of 861 frames; Voicebox one CFG-doubled NFE "
+                      "at 6 of 24 layers (x4 x63); Mistral one of 32 layers bf16, 128-token prefill + 3 decode steps "
+                      "(x32 layers, scaled to 1777 prompt + 564 generated tokens); XLS-R conv stack on 2 s (x5) + 1 encoder "
+                      "layer at 499 frames (x35) + k-means"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pipe = Pipeline(dev, rank, world, group, args)
+    for _ in range(args.warmup):
+        audio = pipe.step()
+    barrier()
+    t0 = time.perf_counter()
+    stage_acc = None
+    for _ in range(args.steps):
+        audio = pipe.step()
+        if stage_acc is None:
+            stage_acc = pipe.ev
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stages = pipe.stage_ms()  # last step
+    audio_s = audio.shape[0] / 22050.0
+    ms_per_step = dt * 1e3 / args.steps
+    llm_ms = stages["llm_asr"] + stages["llm_t2t"] + stages["llm_tts"]
+    res = {
+        "metric": METRIC, "value": round(audio_s * args.steps / dt, 4), "unit": "x real-time (output audio s / wall s)",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "dtype_detail": "LLM + Voicebox: bf16 MFMA operands, f32 accumulate; tokenizer + vocoder: exact f32 MFMA"
+                 if args.vocoder_dtype == "f32" else "LLM + Voicebox + vocoder convs bf16 MFMA; tokenizer f32",
+        "data": "synthetic",
+        "config": {"workload": "full pipeline, one 10 s utterance: XLS-R tokenizer -> Mistral-7B (3 greedy rounds) -> "
+                               "Token-Voicebox 63 NFE (Heun, CFG, 3 s prompt) -> BigVGAN",
+                   "wave_samples": 160000, "prompt_tokens": list(pipe.prompt_lens), "generated_tokens": pipe.n_generated,
+                   "voicebox_n_timesteps": args.nt, "mel_frames": pipe.frames, "output_samples": int(audio.shape[0]),
+                   "parallelism": f"tp{world} (LLM) + replicas"},
+        "llm_tokens_per_s": round(pipe.n_generated / (llm_ms * 1e-3), 2),
+        "llm_decode_tokens_per_s_tts_round": round(args.units / (stages["llm_tts"] * 1e-3), 2),
+        "stage_ms": {k: round(v, 2) for k, v in stages.items()},
+        "model_build_s": round(pipe.build_s, 1),
+    }
+    if rank == 0:
+        res["roofline"] = measure_gemv_roofline(pipe.llm)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+    elif world > 1:
+        measure_gemv_roofline(pipe.llm)  # collectives inside the TP decode need every rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
