@@ -145,14 +145,29 @@ def measure_gemv_roofline(llm):
             "algorithmic_bytes_per_token": int(nbytes)}
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the cgroup CPU quota if one is set, else the affinity mask,
+    capped at 16 (the CPU share of a one-GPU box; more threads only oversubscribe it)."""
+    n = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, int(int(q) / int(p)))
+    except Exception:
+        pass
+    if n is None:
+        try:
+            n = len(os.sched_getaffinity(0))
+        except Exception:
+            n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(args):
     """CPU oracle (kind 'port') on the host cores over a bounded sample; each stage extrapolated as stated."""
     import math
     from oracle import bigvgan_oracle as BO, mistral_oracle as MO, voicebox_oracle as VO, w2v_oracle as WO
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     out = {}
     with torch.no_grad():

@@ -229,7 +229,8 @@ typedef struct usdm_decode_state {
 /* arg-max over the per-block partials (ties -> lowest id = torch.argmax on the masked logits; with
  * do_sample=True, top_k=1 the reference samples among exact ties, of which this is one outcome). */
 int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
-                      const usdm_decode_state* st, usdm_stream_t stream);
+                      const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd, void* h_out_bf16,
+                      usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input) */
 
 /* out[r][:] = table[ids[r]][:] (bf16 rows; ids == NULL -> single row from *next_token) */
 int usdm_embed_rows(const void* table, const int64_t* ids, const int32_t* next_token, int32_t n, int32_t Hd,

@@ -54,12 +54,15 @@ def test_gemv_swiglu_and_argmax(dev):
     ops.gemv(W.to(dev), x.to(dev), N=V, K=K, ban=ban.to(dev), part_val=pv, part_idx=pi, y32=lg, idx_offset=0)
     i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
     nxt, out, step, pos = i32(1), i32(8), i32(1), i32(1)
-    ops.argmax_final(pv, pi, nb, ops.decode_state(nxt, out, step, pos))
+    E = _r((V, 64), 9).to(bf).to(dev)
+    hrow = torch.zeros(64, dtype=bf, device=dev)
+    ops.argmax_final(pv, pi, nb, ops.decode_state(nxt, out, step, pos), embed=E, h_out=hrow, Hd=64)
     masked = logits.clone()
     masked[ban.bool()] = -float("inf")
     got = int(nxt.item())
     assert masked[got] >= masked.max() - 1e-6 and ban[got] == 0
     assert int(step.item()) == 1 and int(pos.item()) == 1 and int(out[0].item()) == got
+    assert torch.equal(hrow, E[got])
     fin = torch.isfinite(masked)
     assert (lg.cpu()[fin] - masked[fin]).abs().max() <= 2e-2 * masked[fin].abs().max()
 

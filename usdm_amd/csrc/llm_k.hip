@@ -22,20 +22,74 @@ __device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// GEMV: y = W x, W bf16 [N][ldw] row-major (the nn.Linear layout), one workgroup per 16 output rows
-// (32 packed rows for SwiGLU), wave = 4 rows at a time, lanes stride K in 16-B pieces.
+// GEMV: y = W x, W bf16 [N][ldw] row-major (the nn.Linear layout).
+//   * workgroup = 4 waves; a wave owns RW output rows (GLU: RW gate + RW up rows) and streams them
+//     together, lanes striding K in 16-B pieces, non-temporal loads;
+//   * a ring of UNR K-iterations per row is always in flight (NR*UNR 16-B loads per lane), and the first
+//     ring is issued BEFORE x is staged / RMS-normalised into LDS, so the prologue hides under HBM latency;
+//   * RW is chosen by the launcher so that the grid is a whole number of workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int GV_ROWS = 16;
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(t);
+}
+// wave64 all-reduce sum without LDS traffic: DPP inside 16-lane rows, v_permlane{16,32}_swap across rows
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_xadd<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_xadd<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_xadd<0x141>(v);  // row_half_mirror
+  v = dpp_xadd<0x140>(v);  // row_mirror
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
+template <int RW, bool GLU>
 __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
+  constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
+  constexpr int UNR = (NR >= 4) ? 4 : (NR == 3 ? 5 : 8);  // ring depth: NR*UNR = 15..16 loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* xs = (bf16_t*)smem;                       // [Kpad] bf16
+  bf16_t* xs = (bf16_t*)smem;  // [Kpad] bf16, zero padded
+  __shared__ float red[4];
+  __shared__ float sv[4];
+  __shared__ int si[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
-  __shared__ float red[8];
+  const int nit = Kpad >> 9;
 
-  // ---- stage x into LDS (optionally fused RMSNorm with HF rounding)
+  // ---- rows of this wave
+  const int rows_per_block = 4 * RW;                      // output features per workgroup
+  const int ob = blockIdx.x * rows_per_block + wave * RW; // first output feature of this wave
+  const u32x4* wp[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    int r;
+    if (GLU) {  // packed layout: blocks of 32 rows = 16 gate + 16 up
+      const int o = ob + (j % RW);
+      r = (o >> 4) * 32 + (o & 15) + (j >= RW ? 16 : 0);
+    } else {
+      r = ob + j;
+    }
+    r = r < a.N ? r : a.N - 1;
+    wp[j] = (const u32x4*)((const bf16_t*)a.W + (int64_t)r * a.ldw) + lane;
+  }
+  const bool tail_ok = ((nit - 1) << 9) + lane * 8 < K;  // is this lane inside K on the last iteration?
+  auto wload = [&](int j, int it) -> u32x4 {
+    // last iteration may run past K: redirect to the row start (x is zero there in LDS, contributes 0)
+    const u32x4* p = (it == nit - 1 && !tail_ok) ? wp[j] - lane : wp[j] + it * 64;
+    return __builtin_nontemporal_load(p);
+  };
+  u32x4 ring[NR][UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      if (u < nit) ring[j][u] = wload(j, u);
+
+  // ---- stage x into LDS (optionally fused RMSNorm with HF rounding) while the first ring is in flight
   const bf16_t* xg = (const bf16_t*)a.x;
   if (a.norm_w) {
     float ss = 0.f;
@@ -47,7 +101,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
         ss += lo * lo + hi * hi;
       }
     }
-    ss = wave_sum(ss);
+    ss = wave_sum_dpp(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
@@ -56,12 +110,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
       u32x4 o = {0, 0, 0, 0};
       if (i < K) {
         const u32x4 v = *(const u32x4*)(xg + i);
+        const float4 g0 = *(const float4*)(a.norm_w + i), g1 = *(const float4*)(a.norm_w + i + 4);
+        const float gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float lo = bf2f(v[e] & 0xffff), hi = bf2f(v[e] >> 16);
-          const float nlo = round_bf(round_bf(lo * rstd) * a.norm_w[i + 2 * e]);
-          const float nhi = round_bf(round_bf(hi * rstd) * a.norm_w[i + 2 * e + 1]);
-          o[e] = pack_bf2(nlo, nhi);
+          o[e] = pack_bf2(round_bf(round_bf(lo * rstd) * gw[2 * e]), round_bf(round_bf(hi * rstd) * gw[2 * e + 1]));
         }
       }
       *(u32x4*)(xs + i) = o;
@@ -75,76 +129,42 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
   }
   __syncthreads();
 
-  const bool glu = a.act == USDM_ACT_SWIGLU;
-  const int rows_per_block = glu ? 2 * GV_ROWS : GV_ROWS;
-  const int rb = blockIdx.x * rows_per_block;
-  // the 4 rows of this wave; for GLU: rows (g0, g1, u0, u1) = gate rows 2w,2w+1 ... handled as two passes
-  const int npass = glu ? 2 : 1;
-  float outv[4] = {0.f, 0.f, 0.f, 0.f};
-  float gatev[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int pass = 0; pass < npass; ++pass) {
-    int r[4];
+  // ---- stream: consume ring slot, immediately refill it UNR iterations ahead
+  float acc[NR];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = rb + pass * GV_ROWS + wave * 4 + j;
-    const u32x4* wp[4];
+  for (int j = 0; j < NR; ++j) acc[j] = 0.f;
+  for (int it0 = 0; it0 < nit; it0 += UNR) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rr = r[j] < a.N ? r[j] : a.N - 1;
-      wp[j] = (const u32x4*)((const bf16_t*)a.W + (int64_t)rr * a.ldw) + lane;
-    }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int nfull = K >> 9;
-    int it = 0;
-    for (; it + 2 <= nfull; it += 2) {
-      u32x4 w0[4], w1[4];
+    for (int u = 0; u < UNR; ++u) {
+      const int it = it0 + u;
+      if (it < nit) {
+        const u32x4 xv = *(const u32x4*)(xs + (it * 64 + lane) * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        w0[j] = __builtin_nontemporal_load(wp[j] + it * 64);
-        w1[j] = __builtin_nontemporal_load(wp[j] + (it + 1) * 64);
+        for (int j = 0; j < NR; ++j) {
+          acc[j] = dot8(ring[j][u], xv, acc[j]);
+          if (it + UNR < nit) ring[j][u] = wload(j, it + UNR);
+        }
       }
-      const u32x4 x0 = *(const u32x4*)(xs + (it * 64 + lane) * 8);
-      const u32x4 x1 = *(const u32x4*)(xs + ((it + 1) * 64 + lane) * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = dot8(w1[j], x1, dot8(w0[j], x0, acc[j]));
-    }
-    for (; it < nfull; ++it) {
-      const u32x4 x0 = *(const u32x4*)(xs + (it * 64 + lane) * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = dot8(__builtin_nontemporal_load(wp[j] + it * 64), x0, acc[j]);
-    }
-    if ((nfull << 9) + lane * 8 < K) {  // K tail (K % 8 == 0)
-      const u32x4 x0 = *(const u32x4*)(xs + (nfull * 64 + lane) * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = dot8(__builtin_nontemporal_load(wp[j] + nfull * 64), x0, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
-    if (glu && pass == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gatev[j] = acc[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) outv[j] = acc[j];
     }
   }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) acc[j] = wave_sum_dpp(acc[j]);
 
-  // ---- epilogue (lane 0 of each wave owns the wave's 4 outputs)
+  // ---- epilogue
   if (a.part_val) {  // lm_head: bf16-rounded logits, ban mask, per-block arg-max (ties -> lowest id)
     float bv = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = rb + wave * 4 + j;
+    for (int j = 0; j < NR; ++j) {
+      const int n = ob + j;
       if (n < a.N && !(a.ban && a.ban[n])) {
-        const float v = round_bf(outv[j]);
-        if (a.y32) { if (lane == 0) a.y32[n] = v; }
+        const float v = round_bf(acc[j]);
+        if (a.y32 && lane == 0) a.y32[n] = v;
         if (v > bv) { bv = v; bi = n; }
       } else if (n < a.N && a.y32 && lane == 0) {
         a.y32[n] = -INFINITY;
       }
     }
-    __shared__ float sv[4];
-    __shared__ int si[4];
     if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -156,25 +176,28 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
     return;
   }
   if (lane != 0) return;
+  if (GLU) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (glu) {
-      const int nout = blockIdx.x * GV_ROWS + wave * 4 + j;
-      const int ngate = rb + wave * 4 + j;
-      if (ngate >= a.N) continue;
-      float o;
+    for (int j = 0; j < RW; ++j) {
+      const int o = ob + j;
+      if (2 * o >= a.N) continue;
+      const float g = acc[j], u = acc[j + RW];
+      float r;
       if (a.round_bf16) {
-        const float gt = round_bf(gatev[j]), up = round_bf(outv[j]);
-        o = round_bf(round_bf(gt / (1.0f + __expf(-gt))) * up);
+        const float gt = round_bf(g), up = round_bf(u);
+        r = round_bf(round_bf(gt / (1.0f + __expf(-gt))) * up);
       } else {
-        o = (gatev[j] / (1.0f + __expf(-gatev[j]))) * outv[j];
+        r = (g / (1.0f + __expf(-g))) * u;
       }
-      if (a.y16) ((bf16_t*)a.y16)[nout] = f2bf(o);
-      if (a.y32) a.y32[nout] = o;
-    } else {
-      const int n = rb + wave * 4 + j;
+      if (a.y16) ((bf16_t*)a.y16)[o] = f2bf(r);
+      if (a.y32) a.y32[o] = r;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int n = ob + j;
       if (n >= a.N) continue;
-      float v = outv[j];
+      float v = acc[j];
       if (a.round_bf16) v = round_bf(v);
       if (a.residual) {
         v += bf2f(((const bf16_t*)a.residual)[n]);
@@ -186,10 +209,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
   }
 }
 
+// Rows per wave: HBM streaming wants >= ~4 workgroups (16 waves) per CU in flight AND a grid that is a whole
+// number of workgroups per CU (256 CUs); take the largest RW that gives both, else the best balanced one.
+static int gemv_pick_rw(int nout, bool glu) {
+  const int ncand = glu ? 2 : 4;
+  const int cands[4] = {glu ? 2 : 4, glu ? 1 : 3, 2, 1};
+  int best = cands[ncand - 1];
+  double best_score = -1.0;
+  for (int c = 0; c < ncand; ++c) {
+    const int rw = cands[c];
+    const int blocks = cdiv(nout, 4 * rw);
+    const double eff = (blocks / 256.0) / (double)((blocks + 255) / 256);  // 1.0 = perfectly balanced
+    if (blocks >= 1024 && eff >= 0.9) return rw;
+    const double score = eff * (blocks >= 512 ? 1.0 : 0.5 + blocks / 1024.0);
+    if (score > best_score) { best_score = score; best = rw; }
+  }
+  return best;
+}
+
 // final arg-max over the per-block partials; advances the device-side decode state
-__global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, usdm_decode_state st) {
+__global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, usdm_decode_state st, const bf16_t* E, int Hd,
+                                    bf16_t* h_out) {
   __shared__ float sv[256];
   __shared__ int si[256];
+  __shared__ int s_tok;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -214,6 +257,13 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
     if (step < st.max_out) st.out_tokens[step] = tok;
     *st.step = step + 1;
     if (st.advance_pos) *st.pos = *st.pos + 1;
+    s_tok = tok;
+  }
+  if (E) {  // fused nn.Embedding lookup of the token the next decode step consumes
+    __syncthreads();
+    const u32x4* src = (const u32x4*)(E + (int64_t)s_tok * Hd);
+    u32x4* dst = (u32x4*)h_out;
+    for (int i = threadIdx.x; i < Hd / 8; i += 256) dst[i] = src[i];
   }
 }
 
@@ -396,17 +446,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   }
 }
 
-__global__ void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out) {
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out) {
+  __shared__ float w[64];
+  __shared__ float linv;
   const int hq = blockIdx.x, d = threadIdx.x;  // 128 threads
-  float m = -1e30f;
-  for (int s = 0; s < NS; ++s) m = fmaxf(m, pm[hq * NS + s]);
-  float l = 0.f, o = 0.f;
-  for (int s = 0; s < NS; ++s) {
-    const float w = __expf(pm[hq * NS + s] - m);
-    l += pl[hq * NS + s] * w;
-    o += po[((int64_t)hq * NS + s) * 128 + d] * w;
+  if (d < 64) {
+    const float mv = d < NS ? pm[hq * NS + d] : -1e30f;
+    const float m = wave_max(mv);
+    const float e = d < NS ? __expf(mv - m) : 0.f;
+    const float l = wave_sum(d < NS ? pl[hq * NS + d] * e : 0.f);
+    w[d] = e;
+    if (d == 0) linv = 1.0f / l;
   }
-  out[hq * 128 + d] = f2bf(o / l);
+  __syncthreads();
+  const float* p = po + (int64_t)hq * NS * 128 + d;
+  float o = 0.f;
+  int s = 0;
+  for (; s + 4 <= NS; s += 4) {
+    const float a0 = p[(s + 0) * 128], a1 = p[(s + 1) * 128], a2 = p[(s + 2) * 128], a3 = p[(s + 3) * 128];
+    o += (a0 * w[s] + a1 * w[s + 1]) + (a2 * w[s + 2] + a3 * w[s + 3]);
+  }
+  for (; s < NS; ++s) o += p[s * 128] * w[s];
+  out[hq * 128 + d] = f2bf(o * linv);
 }
 
 // h = bf16(h + bf16(delta))  — residual add after a tensor-parallel all-reduce of fp32 partial sums
@@ -424,20 +485,36 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   const bool glu = a.act == USDM_ACT_SWIGLU;
   USDM_CHECK_ARG(!glu || a.N % 32 == 0, "usdm_gemv: swiglu needs N %% 32 == 0");
   USDM_CHECK_ARG(a.y16 || a.y32 || a.part_val, "usdm_gemv: no output");
-  USDM_CHECK_ARG(!a.part_val || a.part_idx, "usdm_gemv: part_idx missing");
-  const int rows = glu ? 2 * GV_ROWS : GV_ROWS;
+  USDM_CHECK_ARG(!a.part_val || (a.part_idx && !glu), "usdm_gemv: part_idx missing / lm_head mode is not GLU");
+  USDM_CHECK_ARG(!a.norm_w || a.K % 8 == 0, "usdm_gemv: K");
+  const int nout = glu ? a.N / 2 : a.N;
+  const int rw = a.part_val ? 4 : gemv_pick_rw(nout, glu);
   const int Kpad = (a.K + 511) & ~511;
-  hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(a.N, rows)), dim3(256), Kpad * 2, (hipStream_t)stream, a);
+  dim3 grid(cdiv(nout, 4 * rw)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)Kpad * 2;
+  if (glu) {
+    if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, true>), grid, block, lds, st, a);
+  } else {
+    if (rw == 4) hipLaunchKernelGGL((gemv_kernel<4, false>), grid, block, lds, st, a);
+    else if (rw == 3) hipLaunchKernelGGL((gemv_kernel<3, false>), grid, block, lds, st, a);
+    else if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, false>), grid, block, lds, st, a);
+  }
   USDM_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int usdm_gemv_nblocks(int32_t N, int32_t act) { return cdiv(N, act == USDM_ACT_SWIGLU ? 2 * GV_ROWS : GV_ROWS); }
+extern "C" int usdm_gemv_nblocks(int32_t N, int32_t act) { return cdiv(N, 16); }
 
 extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
-                                 const usdm_decode_state* st, usdm_stream_t stream) {
+                                 const usdm_decode_state* st, const void* embed_table, int32_t Hd, void* h_out,
+                                 usdm_stream_t stream) {
   USDM_CHECK_ARG(part_val && part_idx && nparts > 0 && st && st->next_token && st->out_tokens && st->step && st->pos,
                  "usdm_argmax_final: bad args");
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st);
+  USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_argmax_final: embedding output missing");
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st,
+                     (const bf16_t*)embed_table, Hd, (bf16_t*)h_out);
   USDM_LAUNCH_CHECK();
   return 0;
 }
@@ -464,7 +541,7 @@ extern "C" int usdm_rope_cache(const usdm_rope_args* pa, usdm_stream_t stream) {
 extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && pa->pm && pa->pl && pa->po && pa->out, "usdm_attn_decode: null args");
   const usdm_attn_decode_args& a = *pa;
-  USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0, "usdm_attn_decode: heads");
+  USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0 && a.NS <= 64, "usdm_attn_decode: heads / NS (<= 64)");
   USDM_CHECK_ARG(cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
   const int G = a.Hq / a.Hkv;
   dim3 grid(a.Hkv, a.NS);

@@ -142,6 +142,7 @@ class USDMForCausalLM:
         self.st_out = i32(self.max_out)
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
+        self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
         self.nparts = ops.gemv_nblocks(self.v1 - self.v0)
         self.part_val = torch.zeros(self.nparts * self.tp_size, dtype=torch.float32, device=dev)
         self.part_idx = torch.zeros(self.nparts * self.tp_size, dtype=torch.int32, device=dev)
@@ -169,7 +170,9 @@ class USDMForCausalLM:
             segs.append(plan)
             segs.append(self._gather_partials)
             plan = ops.Plan()
-        ops.argmax_final(self.part_val, self.part_idx, self.nparts * self.tp_size, st, plan=plan)
+        # the picked token's embedding row is written straight into the decode step's input vector
+        ops.argmax_final(self.part_val, self.part_idx, self.nparts * self.tp_size, st, embed=self.W["embed"], h_out=self.h_dec,
+                         Hd=c["hidden_size"], plan=plan)
         plan.hold(st)
         segs.append(plan)
 
@@ -223,11 +226,10 @@ class USDMForCausalLM:
         nq = (Hq + 2 * Hkv) * d
         segs, plan = [], ops.Plan()
         Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
-        h, qkv, ao, act = Z(H), Z(nq), Z(Hq * d), Z(I)
+        h, qkv, ao, act = self.h_dec, Z(nq), Z(Hq * d), Z(I)
         pm, pl, po = Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS * d, dt=torch.float32)
         part = Z(H, dt=torch.float32) if tp > 1 else None
-        ops.embed_rows(self.W["embed"], h, Hd=H, next_token=self.st_next, n=1, plan=plan)
-        for l in range(L):
+        for l in range(L):   # h already holds the embedding of the current token (written by usdm_argmax_final)
             w = self.W["layers"][l]
             ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,

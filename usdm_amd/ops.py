@@ -226,9 +226,10 @@ def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=
     return st
 
 
-def argmax_final(part_val, part_idx, nparts, st, plan=None):
-    _need_cuda(part_val, part_idx)
-    _go(plan, "usdm_argmax_final", lib.usdm_argmax_final, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st))
+def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, plan=None):
+    _need_cuda(part_val, part_idx, embed, h_out)
+    _go(plan, "usdm_argmax_final", lib.usdm_argmax_final, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st),
+        _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 
 def embed_rows(table, out, *, Hd, ids=None, next_token=None, n=1, plan=None):
