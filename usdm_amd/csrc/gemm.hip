@@ -9,10 +9,16 @@
 //   * global -> VGPR (16-B raw buffer loads; out-of-range rows are redirected to an out-of-bounds
 //     offset so the hardware range check returns zeros: no divergent branches) -> XOR-swizzled LDS
 //     (conflict-free ds_read_b128 for the 16x16 MFMA fragment shape) -> MFMA.
-//   * register prefetch of K-step k+1 is in flight while K-step k is multiplied.
+//   * two LDS stages, ONE barrier per K-step: the loads of step k+2 are issued, and step k+1 is
+//     written to the other stage, while step k is multiplied.
 //   * bf16: v_mfma_f32_16x16x32_bf16 ; f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
+//   * epilogue through LDS: the accumulator tile is transposed in LDS so that bias / activation /
+//     residual / rounding run on 4 consecutive outputs per thread and every global access is
+//     8-16 B wide (row-major, transposed, head-split QKV and SwiGLU layouts alike).
 #include "common.h"
 #include "../../include/usdm_hip.h"
+#include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -21,8 +27,26 @@ struct GemmDev {
   int tiles_m, tiles_n;
 };
 
-// LDS image of one operand: [sub-chunk 0..1][row][4 pieces of 16 B], piece index XOR f(row).
+// compile-time loop: every accumulator index below is a constant, so nothing can fall into scratch
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// LDS image of one operand stage: [sub-chunk 0..1][row][4 pieces of 16 B], piece index XOR f(row).
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+
+__device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
+  if (rbf) {
+    g = round_bf(g); u = round_bf(u);
+    return round_bf(round_bf(g / (1.0f + __expf(-g))) * u);
+  }
+  return (g / (1.0f + __expf(-g))) * u;
+}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
@@ -32,17 +56,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   constexpr int PE = 16 / ES;         // elements per 16-B piece
   constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 MFMA tiles per wave
   constexpr int LA = BM / 32, LB = BN / 32;  // 16-B loads per thread per K-step
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128];
-  char* sA = smem;
-  char* sB = smem + BM * 128;
+  constexpr int STAGE = (BM + BN) * 128;     // bytes per LDS stage
+  constexpr int CST = BN + 4;                // f32 row stride of the epilogue tile (bank-conflict-free)
+  constexpr int EPI = BM * CST * 4;
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lc = lane >> 4;
 
-  // tile mapping: consecutive blocks walk N first (share the A row panel)
-  const int tile = blockIdx.x;
+  // tile mapping: blocks that share an XCD (blockIdx % 8) get consecutive tiles; N is walked first
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
@@ -88,7 +119,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
     }
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * 128;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int r = r0 + 32 * i;
@@ -102,16 +135,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   };
 
   f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
 
   load_regs(0);
+  store_lds(0);
+  if (nks > 1) load_regs(1);
+  __syncthreads();
   for (int ks = 0; ks < nks; ++ks) {
-    store_lds();
-    __syncthreads();
-    if (ks + 1 < nks) load_regs(ks + 1);
+    const char* sA = smem + (ks & 1) * STAGE;
+    const char* sB = sA + BM * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 fa[TM], fb[TN];
@@ -125,113 +157,169 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
         const int r = wn * (BN / 2) + j * 16 + lr;
         fb[j] = *(const u32x4*)(sB + s * (BN * 64) + r * 64 + ((lc ^ swz(r)) << 4));
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
+      static_for<TM>([&](auto I) {
+        static_for<TN>([&](auto J) {
           if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+            acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
+                                                                acc[I][J], 0, 0, 0);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               // NB: bit_cast of a vector-element lvalue reads element 0; go through scalars.
-              const unsigned ua = fa[i][e], ub = fb[j][e];
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub), acc[i][j], 0, 0, 0);
+              const unsigned ua = fa[I][e], ub = fb[J][e];
+              acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub), acc[I][J], 0, 0, 0);
             }
           }
-        }
+        });
+      });
     }
+    if (ks + 1 < nks) store_lds((ks + 1) & 1);   // regs hold step ks+1 (issued one step ago)
+    if (ks + 2 < nks) load_regs(ks + 2);
     __syncthreads();
   }
 
-  // ------------------------------------------------------------------ epilogue
+  // ------------------------------------------------------------------ epilogue through LDS
+  float* ct = (float*)smem;  // [BM][CST] f32
+  static_for<TM>([&](auto I) {
+    static_for<TN>([&](auto J) {
+      const int col = wn * (BN / 2) + J * 16 + lr;
+      const int row = wm * (BM / 2) + I * 16 + lc * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ct[(row + e) * CST + col] = acc[I][J][e];
+    });
+  });
+  __syncthreads();
+
   const int gcol = a.c_gcol * gz;
   const float* bias = a.bias;
+  const bool rbf = a.round_bf16 != 0;
+  const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
+
   if (a.act == USDM_ACT_SWIGLU) {
-    // tiles (2p, 2p+1) of a wave hold gate/up for the same 16 output features
+    // column tiles (2p, 2p+1) of 16 hold gate / up of the same 16 output features
+    constexpr int OC = BN / 2;  // output columns of this tile
+    for (int idx = tid; idx < BM * (OC / 4); idx += 256) {
+      const int r = idx / (OC / 4), c4 = (idx - r * (OC / 4)) * 4;
+      const int m = m0 + r;
+      const int cg = (c4 >> 4) * 32 + (c4 & 15);   // gate column inside the tile
+      const int ngate = n0 + cg;
+      if (m >= a.M || ngate >= a.N) continue;
+      const float4 gv = *(const float4*)(ct + r * CST + cg), uv = *(const float4*)(ct + r * CST + cg + 16);
+      float gt[4] = {gv.x, gv.y, gv.z, gv.w}, up[4] = {uv.x, uv.y, uv.z, uv.w}, o[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; j += 2) {
-        const int nt = (n0 + wn * (BN / 2) + j * 16) >> 5;  // pair index
-        const int nout = nt * 16 + lr;
-        const int ngate = n0 + wn * (BN / 2) + j * 16 + lr;
-        if (ngate >= a.N) continue;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int m = m0 + wm * (BM / 2) + i * 16 + lc * 4 + e;
-          if (m >= a.M) continue;
-          float gt = a.alpha * acc[i][j][e], up = a.alpha * acc[i][j + 1][e];
-          if (bias) { gt += bias[gcol + ngate]; up += bias[gcol + ngate + 16]; }
-          float o;
-          if (a.round_bf16) {
-            gt = round_bf(gt); up = round_bf(up);
-            const float s = round_bf(gt / (1.0f + __expf(-gt)));
-            o = round_bf(s * up);
-          } else {
-            o = (gt / (1.0f + __expf(-gt))) * up;
-          }
-          const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-          if (a.C32) ((float*)a.C32)[row * a.ldc + (gcol >> 1) + nout] = o;
-          if (a.C16) ((bf16_t*)a.C16)[row * a.ldc + (gcol >> 1) + nout] = f2bf(o);
-        }
+      for (int e = 0; e < 4; ++e) {
+        float gg = a.alpha * gt[e], uu = a.alpha * up[e];
+        if (bias) { gg += bias[gcol + ngate + e]; uu += bias[gcol + ngate + 16 + e]; }
+        o[e] = silu_mul(gg, uu, rbf);
       }
+      const int nout = (n0 >> 1) + c4;
+      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+      const int64_t oi = row * a.ldc + (gcol >> 1) + nout;
+      if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+    }
     return;
   }
 
+  // value after bias / activation (before residual)
+  auto pre = [&](float x, int n) -> float {
+    x = a.alpha * x + (bias ? bias[gcol + n] : 0.f);
+    if (rbf) x = round_bf(x);
+    if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
+    else if (a.act == USDM_ACT_TANH) x = tanhf(x);
+    return x;
+  };
+
+  const bool col_major_out = a.transpose_out != 0;
+  // ---- pass 1: outputs whose fast axis is n (row-major C, Q and K of the head-split epilogue)
+  if (!col_major_out) {
+    const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
+    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+      const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
+      const int m = m0 + r, n = n0 + c4;
+      if (m >= a.M || n >= a.N) continue;
+      const float4 cv = *(const float4*)(ct + r * CST + c4);
+      float v[4] = {cv.x, cv.y, cv.z, cv.w};
+      const int nv = (a.N - n) < 4 ? (a.N - n) : 4;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + lr;
-      if (n >= a.N) continue;
-      const float bv = bias ? bias[gcol + n] : 0.f;
-      const int mb = m0 + wm * (BM / 2) + i * 16 + lc * 4;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = a.alpha * acc[i][j][e] + bv;
-        if (a.round_bf16) x = round_bf(x);
-        if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
-        else if (a.act == USDM_ACT_TANH) x = tanhf(x);
-        v[e] = x;
-      }
-      if (a.epi == USDM_EPI_QKV_HEADS) {
+      for (int e = 0; e < 4; ++e) v[e] = e < nv ? pre(v[e], n + e) : 0.f;
+      if (is_qkv) {
         const int HD = a.qkv_H * a.qkv_D;
-        const int part = n / HD, hn = n - part * HD;
-        const int h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int m = mb + e;
-          if (m >= a.M) continue;
-          const int b = m / a.qkv_S, s = m - b * a.qkv_S;
-          const int64_t bh = (int64_t)b * a.qkv_H + h;
-          if (part == 0)
-            ((bf16_t*)a.qkv_q)[(bh * a.qkv_Spad + s) * a.qkv_D + d] = f2bf(v[e]);
-          else if (part == 1)
-            ((bf16_t*)a.qkv_k)[(bh * a.qkv_Spad + s) * a.qkv_D + d] = f2bf(v[e]);
-          else
-            ((bf16_t*)a.qkv_v)[(bh * a.qkv_D + d) * a.qkv_Spad + s] = f2bf(v[e]);
-        }
+        const int part = n / HD;
+        if (part == 2) continue;  // V is stored transposed in pass 2
+        const int hn = n - part * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
+        const int b = m / a.qkv_S, s = m - b * a.qkv_S;
+        bf16_t* dst = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k) + (((int64_t)b * a.qkv_H + h) * a.qkv_Spad + s) * a.qkv_D + d;
+        uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
+        *(uint2*)dst = p;   // D % 4 == 0 and N % 4 == 0 are checked on the host
         continue;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = mb + e;
-        if (m >= a.M) continue;
-        const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-        float x = v[e];
-        if (a.residual) {
-          const int64_t ri = row * a.ldr + gcol + n;
-          x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
-          if (a.round_bf16) x = round_bf(x);
+      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+      if (a.residual) {
+        const int64_t ri = row * a.ldr + gcol + n;
+        if (vec_ok && nv == 4) {
+          if (a.res_dtype == USDM_F32) {
+            const float4 rv = *(const float4*)((const float*)a.residual + ri);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          } else {
+            const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+            v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+          }
+        } else {
+          for (int e = 0; e < nv; ++e)
+            v[e] += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri + e] : bf2f(((const bf16_t*)a.residual)[ri + e]);
         }
-        const int64_t oi = a.transpose_out ? ((int64_t)(gcol + n) * a.ldc + row) : (row * a.ldc + gcol + n);
-        if (a.C32) ((float*)a.C32)[oi] = x;
-        if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+        if (rbf) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
+        }
+      }
+      const int64_t oi = row * a.ldc + gcol + n;
+      if (vec_ok && nv == 4) {
+        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+      } else {
+        for (int e = 0; e < nv; ++e) {
+          if (a.C32) ((float*)a.C32)[oi + e] = v[e];
+          if (a.C16) ((bf16_t*)a.C16)[oi + e] = f2bf(v[e]);
+        }
       }
     }
+    if (!is_qkv) return;
+  }
+  // ---- pass 2: outputs whose fast axis is m (transpose_out, V^T of the head-split epilogue)
+  for (int idx = tid; idx < BN * (BM / 4); idx += 256) {
+    const int c = idx / (BM / 4), r4 = (idx - c * (BM / 4)) * 4;
+    const int n = n0 + c, m = m0 + r4;
+    if (n >= a.N || m >= a.M) continue;
+    const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = e < mv ? pre(ct[(r4 + e) * CST + c], n) : 0.f;
+    if (is_qkv) {
+      const int HD = a.qkv_H * a.qkv_D;
+      if (n < 2 * HD) continue;
+      const int hn = n - 2 * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
+      for (int e = 0; e < mv; ++e) {
+        const int mm = m + e, b = mm / a.qkv_S, s = mm - b * a.qkv_S;
+        ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s] = f2bf(v[e]);
+      }
+      continue;
+    }
+    const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+    for (int e = 0; e < mv; ++e) {
+      const int64_t rw = row + (int64_t)e * a.c_row_mul;
+      float x = v[e];
+      if (a.residual) {
+        const int64_t ri = rw * a.ldr + gcol + n;
+        x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+        if (rbf) x = round_bf(x);
+      }
+      const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
+      if (a.C32) ((float*)a.C32)[oi] = x;
+      if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+    }
+  }
 }
 
 template <typename T, int BM, int BN>
@@ -273,21 +361,33 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t wmax = ((int64_t)a.N * a.ldw) * es;
   USDM_CHECK_ARG(amax < 0x7FFFFF00ll && wmax < 0x7FFFFF00ll, "usdm_gemm: operand exceeds 2 GiB addressing window");
   USDM_CHECK_ARG(a.C32 || a.C16 || a.epi == USDM_EPI_QKV_HEADS, "usdm_gemm: no output");
-  if (a.act == USDM_ACT_SWIGLU) USDM_CHECK_ARG(a.N % 32 == 0 && !a.transpose_out && !a.residual, "usdm_gemm: swiglu needs N%%32==0");
+  if (a.act == USDM_ACT_SWIGLU)
+    USDM_CHECK_ARG(a.N % 32 == 0 && !a.transpose_out && !a.residual && a.ldc % 4 == 0 && a.c_gcol % 8 == 0 && a.epi == USDM_EPI_PLAIN,
+                   "usdm_gemm: swiglu needs N%%32==0, ldc%%4==0, row-major output, no residual");
   if (a.epi == USDM_EPI_QKV_HEADS)
-    USDM_CHECK_ARG(a.qkv_q && a.qkv_k && a.qkv_v && a.N == 3 * a.qkv_H * a.qkv_D && a.qkv_S > 0 && a.qkv_Spad >= a.qkv_S,
+    USDM_CHECK_ARG(a.qkv_q && a.qkv_k && a.qkv_v && a.N == 3 * a.qkv_H * a.qkv_D && a.qkv_S > 0 && a.qkv_Spad >= a.qkv_S &&
+                       a.qkv_D % 4 == 0 && !a.transpose_out && !a.residual && a.groups == 1 && a.batch == 1,
                    "usdm_gemm: bad qkv epilogue args");
   hipStream_t st = (hipStream_t)stream;
-  // tile heuristic: fill >= ~2 waves of the 256 CUs when possible
-  const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.groups * a.batch;
-  const bool small_n = a.N <= 64;
+  // tile heuristic from tools/bench_gemm_tiles.py on MI355X (profiles/r01_gemm_tiles.txt): the kernel is L2->LDS
+  // traffic bound, so the big tile wins once there are >= ~2.5 tiles per CU; mid-size problems with wide N take
+  // 128x64; everything else fills the chip best with 64x64.
+  const int64_t z = (int64_t)a.groups * a.batch;
+  const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
+  const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
+  int sel;  // 0: 128x128, 1: 128x64, 2: 64x64
+  if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
+  else if (t128 >= 640) sel = 0;
+  else if (a.N >= 4096 && t12864 >= 448) sel = 1;
+  else sel = 2;
+  if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
   if (a.dtype == USDM_BF16) {
-    if (!small_n && t128 >= 384) return launch<bf16_t, 128, 128>(a, st);
-    if (small_n) return launch<bf16_t, 128, 64>(a, st);
+    if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
+    if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
   } else {
-    if (!small_n && t128 >= 384) return launch<float, 128, 128>(a, st);
-    if (small_n) return launch<float, 128, 64>(a, st);
+    if (sel == 0) return launch<float, 128, 128>(a, st);
+    if (sel == 1) return launch<float, 128, 64>(a, st);
     return launch<float, 64, 64>(a, st);
   }
 }
