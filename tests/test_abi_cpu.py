@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library builds, loads, matches the header struct sizes, and exports every function that
+include/usdm_hip.h declares; the drop-in import paths resolve; CPU tensors are refused (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from usdm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "usdm_hip.h")).read()
+    names = set(re.findall(r"^(?:int|const char\*)\s+(usdm_\w+)\s*\(", hdr, flags=re.M))
+    assert len(names) >= 20, names
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert _lib.lib.usdm_abi_version() >= 1
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    from usdm_amd import _lib
+    a = _lib.GemmArgs()
+    rc = _lib.lib.usdm_gemm(ctypes.byref(a), ctypes.c_void_p(0))
+    assert rc == 2 and b"usdm_gemm" in _lib.lib.usdm_last_error()
+    with pytest.raises(_lib.UsdmError):
+        _lib.check(rc, "usdm_gemm")
+
+
+def test_dropin_paths_and_no_cpu_fallback():
+    import usdm_amd.dropin as D
+    D.install()
+    from seamless_communication.models.unit_extractor import UnitExtractor  # noqa: F401
+    from voicebox.model import Voicebox  # noqa: F401
+    from voicebox.util.model_util import initialize_decoder, mel_mean, mel_std, process_unit, reconstruct_speech  # noqa: F401
+    from voicebox.vocoder.models import BigVGAN  # noqa: F401
+    assert (mel_mean, mel_std) == (-5.5419, 2.1575)
+    from usdm_amd import _lib, ops
+    with pytest.raises(_lib.UsdmError):
+        ops.process_unit(torch.zeros(4, dtype=torch.int64), 441, 256)
+    from usdm_amd.llm import USDMForCausalLM
+    with pytest.raises(RuntimeError):
+        USDMForCausalLM(dict(head_dim=128), "cpu")
+
+
+def test_inference_helpers_match_reference_semantics():
+    from usdm_amd.inference import default_template, generate_bad_words_ids, strip_exact_multiple
+    t = default_template("<|unit1|>", "hi", "yo")
+    assert t.endswith("<|unit1|><|correspond|>hi\n### Agent\nyo<|correspond|>") and t.startswith("Below is a conversation")
+    assert strip_exact_multiple("\n hi \n", ["\n", " "]) == "hi"
+    assert strip_exact_multiple("  hi", [" "]) == " hi"  # one occurrence per pattern, as the reference
+    b = generate_bad_words_ids(0, 32002, exclude=[28705])
+    assert len(b) == 32001 and [28705] not in b and b[0] == [0] and b[-1] == [32001]
+    from oracle.units_oracle import banned_ranges
+    ids = {w[0] for w in b}
+    assert ids == {i for lo, hi in banned_ranges("text2unit") for i in range(lo, hi)}

@@ -147,3 +147,28 @@ def test_first_token_logits_vs_oracle(dev):
     err = (got - ref[-1]).abs().max().item()
     print("prefill logits max err", err, "scale", ref[-1].abs().max().item())
     assert err <= 4e-2 * ref[-1].abs().max().item()
+
+
+def test_tp_code_path_single_rank_nccl(dev):
+    """The tensor-parallel code path (f32 partial sums -> RCCL all_reduce / all_gather -> residual-add kernel) on a
+    1-rank 'nccl' group must reproduce the fused single-GPU path token for token."""
+    import os
+    import torch.distributed as dist
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        sd = MO.random_state_dict(SMALL, seed=11)
+        ids = torch.randint(0, SMALL["vocab_size"], (1, 23), generator=torch.Generator().manual_seed(3)).to(dev)
+        a = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128).generate(input_ids=ids, max_new_tokens=12)
+        b = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128, tp_segments=True, group=dist.group.WORLD).generate(
+            input_ids=ids, max_new_tokens=12)
+        assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the tensor-parallel algebra used by usdm_amd.llm (shard_weights + f32 partial
+sums + all_reduce + vocab-parallel arg-max gather) reproduces the unsharded computation."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import shard_weights
+    cfg = dict(vocab_size=203, hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
+               num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-5, rope_theta=10000.0)
+    sd = MO.random_state_dict(cfg, seed=7, dtype=torch.float32)
+    W = shard_weights(lambda n: sd[n], cfg, rank, world, "cpu", dtype=torch.float32)
+    lw = W["layers"][0]
+    x = torch.randn(5, 256, generator=torch.Generator().manual_seed(1))
+    d, Hq, Hkv, I = 64, 4 // world, 2 // world, 512 // world
+    # attention block: local heads, o_proj partial sums all-reduced
+    qkv = x @ lw["qkv"].T
+    q, k, v = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
+    sh = lambda t, h: t.view(5, h, d).transpose(0, 1)
+    att = torch.softmax(sh(q, Hq) @ sh(k, Hkv).repeat_interleave(Hq // Hkv, 0).transpose(1, 2) * d ** -0.5, -1)
+    o = (att @ sh(v, Hkv).repeat_interleave(Hq // Hkv, 0)).transpose(0, 1).reshape(5, Hq * d)
+    part = o @ lw["o"].T
+    dist.all_reduce(part)
+    # reference (unsharded)
+    p = "model.layers.0."
+    qf, kf, vf = x @ sd[p + "self_attn.q_proj.weight"].T, x @ sd[p + "self_attn.k_proj.weight"].T, x @ sd[p + "self_attn.v_proj.weight"].T
+    attf = torch.softmax(sh(qf, 4) @ sh(kf, 2).repeat_interleave(2, 0).transpose(1, 2) * d ** -0.5, -1)
+    of = (attf @ sh(vf, 2).repeat_interleave(2, 0)).transpose(0, 1).reshape(5, 256)
+    ref = of @ sd[p + "self_attn.o_proj.weight"].T
+    ok1 = torch.allclose(part, ref, atol=1e-4)
+    # MLP block: packed gate/up rows (blocks of 16+16), down partial sums
+    gu = x @ lw["gu"].T
+    gu = gu.view(5, I // 16, 2, 16)
+    act = (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(5, I)
+    part = act @ lw["down"].T
+    dist.all_reduce(part)
+    ref = (torch.nn.functional.silu(x @ sd[p + "mlp.gate_proj.weight"].T) * (x @ sd[p + "mlp.up_proj.weight"].T)) @ sd[p + "mlp.down_proj.weight"].T
+    ok2 = torch.allclose(part, ref, atol=1e-4)
+    # vocab-parallel arg-max: local (max, global id) gathered, ties -> lowest id
+    logits = x[0] @ W["lm_head"].T
+    loc = torch.stack([logits.max(), (logits.argmax() + W["v0"]).float()])
+    allv = [torch.zeros(2) for _ in range(world)]
+    dist.all_gather(allv, loc)
+    best = max(allv, key=lambda t: (t[0].item(), -t[1].item()))
+    ok3 = int(best[1].item()) == int((x[0] @ sd["lm_head.weight"].T).argmax())
+    out_q.put((rank, bool(ok1), bool(ok2), bool(ok3)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_tp2_gloo_matches_unsharded():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res

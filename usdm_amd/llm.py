@@ -31,8 +31,36 @@ def _pack_gate_up(gate, up):
     return torch.stack([gate.reshape(I // 16, 16, K), up.reshape(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous()
 
 
+def shard_weights(sd_get, cfg, rank, tp, device, dtype=torch.bfloat16):
+    """This rank's packed weights for tensor parallelism of degree `tp` (Megatron-style): q/k/v heads and MLP
+    columns split by rank, o_proj/down_proj split along K (their outputs are partial sums), vocab rows split."""
+    d = cfg["head_dim"]
+    Hq, Hkv, I = cfg["num_attention_heads"] // tp, cfg["num_key_value_heads"] // tp, cfg["intermediate_size"] // tp
+    V = cfg["vocab_size"]
+    Vloc = (V + tp - 1) // tp
+    v0 = min(V, rank * Vloc)
+    v1 = min(V, v0 + Vloc)
+    g = lambda n: sd_get(n).to(device, dtype)
+    f = lambda n: sd_get(n).to(device, torch.float32).contiguous()
+    W = {"embed": g("model.embed_tokens.weight").contiguous(), "norm": f("model.norm.weight"),
+         "lm_head": g("lm_head.weight")[v0:v1].contiguous(), "layers": [], "v0": v0, "v1": v1}
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{l}."
+        q = g(p + "self_attn.q_proj.weight")[rank * Hq * d:(rank + 1) * Hq * d]
+        k = g(p + "self_attn.k_proj.weight")[rank * Hkv * d:(rank + 1) * Hkv * d]
+        v = g(p + "self_attn.v_proj.weight")[rank * Hkv * d:(rank + 1) * Hkv * d]
+        o = g(p + "self_attn.o_proj.weight")[:, rank * Hq * d:(rank + 1) * Hq * d]
+        ga = g(p + "mlp.gate_proj.weight")[rank * I:(rank + 1) * I]
+        up = g(p + "mlp.up_proj.weight")[rank * I:(rank + 1) * I]
+        dn = g(p + "mlp.down_proj.weight")[:, rank * I:(rank + 1) * I]
+        W["layers"].append(dict(qkv=torch.cat([q, k, v], 0).contiguous(), o=o.contiguous(), gu=_pack_gate_up(ga, up),
+                                down=dn.contiguous(), ln1=f(p + "input_layernorm.weight"),
+                                ln2=f(p + "post_attention_layernorm.weight")))
+    return W
+
+
 class USDMForCausalLM:
-    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=16):
+    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=16, tp_segments=None):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -41,6 +69,9 @@ class USDMForCausalLM:
         if c["head_dim"] != 128:
             raise NotImplementedError("decode/prefill attention kernels are built for head_dim 128 (Mistral-7B)")
         self.tp_rank, self.tp_size, self.group = tp_rank, tp_size, group
+        # tp_segments: run the tensor-parallel code path (f32 partial sums + all-reduce + residual-add kernels) even at
+        # tp_size 1 — used to exercise that path on a single GPU
+        self.tp_path = (tp_size > 1) if tp_segments is None else bool(tp_segments)
         self.Hq, self.Hkv = c["num_attention_heads"] // tp_size, c["num_key_value_heads"] // tp_size
         if self.Hq * tp_size != c["num_attention_heads"] or self.Hkv * tp_size != c["num_key_value_heads"] or self.Hkv < 1:
             raise ValueError("tp_size must divide both head counts")
@@ -63,26 +94,9 @@ class USDMForCausalLM:
 
     # ------------------------------------------------------------------ weights
     def _shard(self, sd_get):
-        """Build this rank's packed weights from a getter name -> bf16 tensor (any device)."""
-        c, dev, bf = self.cfg, self.device, torch.bfloat16
-        d, r = c["head_dim"], self.tp_rank
-        g = lambda n: sd_get(n).to(dev, bf)
-        W = {"embed": g("model.embed_tokens.weight").contiguous(),
-             "norm": sd_get("model.norm.weight").to(dev, torch.float32).contiguous(),
-             "lm_head": g("lm_head.weight")[self.v0:self.v1].contiguous(), "layers": []}
-        for l in range(c["num_hidden_layers"]):
-            p = f"model.layers.{l}."
-            q = g(p + "self_attn.q_proj.weight")[r * self.Hq * d:(r + 1) * self.Hq * d]
-            k = g(p + "self_attn.k_proj.weight")[r * self.Hkv * d:(r + 1) * self.Hkv * d]
-            v = g(p + "self_attn.v_proj.weight")[r * self.Hkv * d:(r + 1) * self.Hkv * d]
-            o = g(p + "self_attn.o_proj.weight")[:, r * self.Hq * d:(r + 1) * self.Hq * d]
-            ga = g(p + "mlp.gate_proj.weight")[r * self.I:(r + 1) * self.I]
-            up = g(p + "mlp.up_proj.weight")[r * self.I:(r + 1) * self.I]
-            dn = g(p + "mlp.down_proj.weight")[:, r * self.I:(r + 1) * self.I]
-            W["layers"].append(dict(
-                qkv=torch.cat([q, k, v], 0).contiguous(), o=o.contiguous(), gu=_pack_gate_up(ga, up), down=dn.contiguous(),
-                ln1=sd_get(p + "input_layernorm.weight").to(dev, torch.float32).contiguous(),
-                ln2=sd_get(p + "post_attention_layernorm.weight").to(dev, torch.float32).contiguous()))
+        """Build this rank's packed weights from a getter name -> tensor (any device)."""
+        W = shard_weights(sd_get, self.cfg, self.tp_rank, self.tp_size, self.device)
+        assert (W["v0"], W["v1"]) == (self.v0, self.v1)
         return W
 
     @classmethod
@@ -146,8 +160,8 @@ class USDMForCausalLM:
         self.nparts = ops.gemv_nblocks(self.v1 - self.v0)
         self.part_val = torch.zeros(self.nparts * self.tp_size, dtype=torch.float32, device=dev)
         self.part_idx = torch.zeros(self.nparts * self.tp_size, dtype=torch.int32, device=dev)
-        self.part_val_loc = torch.zeros(self.nparts, dtype=torch.float32, device=dev) if self.tp_size > 1 else self.part_val
-        self.part_idx_loc = torch.zeros(self.nparts, dtype=torch.int32, device=dev) if self.tp_size > 1 else self.part_idx
+        self.part_val_loc = torch.zeros(self.nparts, dtype=torch.float32, device=dev) if self.tp_path else self.part_val
+        self.part_idx_loc = torch.zeros(self.nparts, dtype=torch.int32, device=dev) if self.tp_path else self.part_idx
 
     # ------------------------------------------------------------------ collectives (TP only)
     def _all_reduce(self, t):
@@ -166,7 +180,7 @@ class USDMForCausalLM:
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
                  y32=self.last_logits if self.keep_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0, plan=plan)
         st = ops.decode_state(self.st_next, self.st_out, self.st_step, self.st_pos, advance_pos=advance_pos)
-        if self.tp_size > 1:
+        if self.tp_path:
             segs.append(plan)
             segs.append(self._gather_partials)
             plan = ops.Plan()
@@ -180,7 +194,7 @@ class USDMForCausalLM:
     def _build_prefill(self, S):
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
-        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, self.tp_size
+        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
         nq = (Hq + 2 * Hkv) * d
         Spad = (S + 63) // 64 * 64
         segs, plan = [], ops.Plan()
@@ -222,7 +236,7 @@ class USDMForCausalLM:
     def _build_decode(self):
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
-        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, self.tp_size
+        Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
         nq = (Hq + 2 * Hkv) * d
         segs, plan = [], ops.Plan()
         Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
