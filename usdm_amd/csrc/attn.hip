@@ -10,6 +10,7 @@
 // straight back as the B operand of O^T += V^T.P^T (no LDS round trip, no cross-lane traffic).
 // V is therefore consumed as V^T [d][key], which the producing GEMM epilogue writes directly.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/usdm_hip.h"
 
 namespace {
@@ -17,20 +18,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int KT = 64;  // keys per tile
 
-template <int DH, int MODE>  // MODE 0: bidirectional + ALiBi + key-length mask ; 1: causal
-__global__ __launch_bounds__(256) void attn_kernel(const usdm_attn_args a) {
+template <int DH, int MODE, int NW>  // MODE 0: bidirectional + ALiBi + key-length mask ; 1: causal ; NW waves x 32 queries
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
+  constexpr int NT = NW * 64;   // threads
+  constexpr int QB = NW * 32;   // queries per workgroup
   constexpr int DS = DH / 16;  // d-steps of QK^T
   constexpr int DT = DH / 32;  // 32-row tiles of O^T
   constexpr int KROW = DH * 2; // bytes per K row
-  __shared__ __attribute__((aligned(16))) char smem[KT * KROW + DH * KT * 2];
-  char* sK = smem;
-  char* sV = smem + KT * KROW;
+  constexpr int STAGE = KT * KROW + DH * KT * 2;  // K tile + V^T tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (a.Hq / a.Hkv);
-  const int q0 = qb * 128 + wave * 32;
+  const int q0 = qb * QB + wave * 32;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
 
   const bf16_t* Q = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
@@ -61,41 +63,43 @@ __global__ __launch_bounds__(256) void attn_kernel(const usdm_attn_args a) {
 
   int kend = kv_len;
   if (MODE == 1) {
-    const int last_q = a.q_pos0 + min(qb * 128 + 127, a.Sq - 1);
+    const int last_q = a.q_pos0 + min(qb * QB + QB - 1, a.Sq - 1);
     kend = min(kv_len, last_q + 1);
   }
   const int ntiles = (kend + KT - 1) / KT;
 
   // loader mapping: K tile = KT rows x (DH/8) 16-B pieces ; V^T tile = DH rows x 8 pieces
-  constexpr int KP = KT * (DH / 8) / 256;  // pieces per thread
-  constexpr int VP = DH * 8 / 256;
+  constexpr int KP = KT * (DH / 8) / NT;  // pieces per thread
+  constexpr int VP = DH * 8 / NT;
   u32x4 rk[KP], rv[VP];
   auto load_tile = [&](int kt) {
     const int k0 = kt * KT;
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NT * i;
       const int row = p / (DH / 8), c = p % (DH / 8);
       rk[i] = *(const u32x4*)(K + (int64_t)(k0 + row) * a.k_rs + c * 8);
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NT * i;
       const int d = p >> 3, c = p & 7;
       rv[i] = *(const u32x4*)(V + (int64_t)d * a.v_ds + k0 + c * 8);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    char* sK = smem + stage * STAGE;
+    char* sV = sK + KT * KROW;
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NT * i;
       const int row = p / (DH / 8), c = p % (DH / 8);
       const int cs = (DH == 64) ? (c ^ ((row >> 1) & 7)) : (c ^ (row & 15));
       *(u32x4*)(sK + row * KROW + cs * 16) = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NT * i;
       const int d = p >> 3, c = p & 7;
       const int f = (d >> 1) & 15;
       u32x2 lo = {rv[i][0], rv[i][1]}, hi = {rv[i][2], rv[i][3]};
@@ -104,11 +108,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const usdm_attn_args a) {
     }
   };
 
-  if (ntiles > 0) load_tile(0);
+  // two LDS stages, one barrier per key tile: tile kt+1 is written to the other stage and tile kt+2 is
+  // in flight from HBM/L2 while tile kt is multiplied
+  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  if (ntiles > 1) load_tile(1);
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const char* sK = smem + (kt & 1) * STAGE;
+    const char* sV = sK + KT * KROW;
 
     // ---- S^T = K . Q^T for the two 32-key sub-tiles
     f32x16 sacc[2];
@@ -125,44 +132,59 @@ __global__ __launch_bounds__(256) void attn_kernel(const usdm_attn_args a) {
         sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
       }
     }
-    // ---- bias, mask, online softmax (log2 domain)
+    // ---- bias, mask, online softmax (log2 domain).  VALU-lean: the key position of register r is a compile-time
+    // constant plus a per-lane offset, masks are applied only on the (wave-uniform) tiles that need them.
+    const int kbase = kt * KT + 4 * lh;                       // kpos(u,r) = kbase + 32u + (r&3) + 8(r>>2)
+    const float fq = (float)(qpos - kbase);                   // qpos - kpos = fq - c(u,r)
     float mloc = -1e30f;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kpos = kt * KT + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float s = sacc[u][r] * sc;
-        bool ok = kpos < kv_len;
-        if (MODE == 0) {
-          const int dlt = qpos > kpos ? qpos - kpos : kpos - qpos;
-          if (kpos != 0 || !a.alibi_col0_zero) s -= slope2 * (float)dlt;
-        } else {
-          ok = ok && (kpos <= qpos);
-        }
-        s = ok ? s : -1e30f;
+        const float c = (float)(32 * u + (r & 3) + 8 * (r >> 2));
+        float s;
+        if (MODE == 0) s = fmaf(sacc[u][r], sc, -slope2 * fabsf(fq - c));
+        else s = sacc[u][r] * sc;
         sacc[u][r] = s;
-        mloc = fmaxf(mloc, s);
       }
+    if (MODE == 0 && kt == 0 && a.alibi_col0_zero) {          // key 0 carries no ALiBi bias (networks.py:327)
+      if (lh == 0) sacc[0][0] = fmaf(sacc[0][0], 1.0f, slope2 * fabsf(fq));
+    }
+    const bool need_mask = (kt * KT + KT > kv_len) || (MODE == 1 && kt * KT + KT - 1 > a.q_pos0 + q0);
+    if (need_mask) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kpos = kbase + 32 * u + (r & 3) + 8 * (r >> 2);
+          const bool ok = (kpos < kv_len) && (MODE == 0 || kpos <= qpos);
+          sacc[u][r] = ok ? sacc[u][r] : -1e30f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[u][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float s = sacc[u][r];
-        const float p = (s > -1e29f) ? exp2f(s - m_new) : 0.f;
+        const float p = __builtin_amdgcn_exp2f(sacc[u][r] - m_new);   // masked scores (-1e30) underflow to exactly 0
         sacc[u][r] = p;
         psum += p;
       }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T   (P^T taken from the accumulator registers as the B operand)
 #pragma unroll
@@ -183,6 +205,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const usdm_attn_args a) {
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[t], 0, 0, 0);
         }
       }
+    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
+    if (kt + 2 < ntiles) load_tile(kt + 2);
     __syncthreads();
   }
 
@@ -214,12 +238,21 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.Skv_alloc >= cdiv(a.Skv, KT) * KT, "usdm_attention: K/V^T buffers must be allocated (and finite) up to a multiple of %d keys", KT);
   USDM_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_ds % 8 == 0 && a.o_rs % 4 == 0, "usdm_attention: strides break 16-B alignment");
   USDM_CHECK_ARG(a.mode == 0 || a.mode == 1, "usdm_attention: mode");
-  dim3 grid(cdiv(a.Sq, 128), a.Hq, a.B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (a.dh == 64 && a.mode == 0) hipLaunchKernelGGL((attn_kernel<64, 0>), grid, block, 0, st, a);
-  else if (a.dh == 64) hipLaunchKernelGGL((attn_kernel<64, 1>), grid, block, 0, st, a);
-  else if (a.mode == 0) hipLaunchKernelGGL((attn_kernel<128, 0>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((attn_kernel<128, 1>), grid, block, 0, st, a);
+  // 2-wave workgroups (64 queries) when 4-wave ones would leave CUs with a single resident workgroup
+  const bool small = getenv("USDM_ATTN_NW2") && (int64_t)cdiv(a.Sq, 128) * a.Hq * a.B < 1024;
+  const int qb = small ? 64 : 128;
+  dim3 grid(cdiv(a.Sq, qb), a.Hq, a.B), block(small ? 128 : 256);
+#define USDM_ATTN(DHV, MODEV)                                                                 \
+  do {                                                                                         \
+    if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a);        \
+    else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a);              \
+  } while (0)
+  if (a.dh == 64 && a.mode == 0) USDM_ATTN(64, 0);
+  else if (a.dh == 64) USDM_ATTN(64, 1);
+  else if (a.mode == 0) USDM_ATTN(128, 0);
+  else USDM_ATTN(128, 1);
+#undef USDM_ATTN
   USDM_LAUNCH_CHECK();
   return 0;
 }

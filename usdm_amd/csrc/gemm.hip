@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   const unsigned lda_b = (unsigned)(a.lda * ES), ldw_b = (unsigned)(a.ldw * ES);
   const unsigned OOB = 0xFFFFFFF0u;
 
-  u32x4 ra[LA], rb[LB];
+  u32x4 ra0[LA], rb0[LB], ra1[LA], rb1[LB];  // two register stages: loads run two K-steps ahead of the MFMAs
 
-  auto load_regs = [&](int ks) {
+  auto load_regs = [&](int ks, u32x4* ra, u32x4* rb) {
     const int q = 2 * ks + sub;
     const bool qv = q < Q;
     const int tap = q / cpt;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
     }
   };
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage, const u32x4* ra, const u32x4* rb) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + BM * 128;
 #pragma unroll
@@ -137,12 +137,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
 
-  load_regs(0);
-  store_lds(0);
-  if (nks > 1) load_regs(1);
-  __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
-    const char* sA = smem + (ks & 1) * STAGE;
+  auto compute = [&](int stage) {
+    const char* sA = smem + stage * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -173,9 +169,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
         });
       });
     }
-    if (ks + 1 < nks) store_lds((ks + 1) & 1);   // regs hold step ks+1 (issued one step ago)
-    if (ks + 2 < nks) load_regs(ks + 2);
+  };
+
+  // software pipeline: LDS stage (ks & 1) is multiplied while step ks+1 is written to the other stage.
+  // Small tiles (cheap in registers, short MFMA phase) keep TWO K-steps of loads in flight in two register
+  // sets; the 128x128 tile keeps one (a second set would halve its occupancy: measured slower).
+  constexpr bool PF2 = (BM * BN <= 128 * 64);
+  load_regs(0, ra0, rb0);
+  store_lds(0, ra0, rb0);
+  if (nks > 1) load_regs(1, ra0, rb0);
+  if constexpr (PF2) {
+    if (nks > 2) load_regs(2, ra1, rb1);
     __syncthreads();
+    for (int ks = 0; ks < nks; ks += 2) {
+      compute(0);
+      if (ks + 1 < nks) store_lds(1, ra0, rb0);
+      if (ks + 3 < nks) load_regs(ks + 3, ra0, rb0);
+      __syncthreads();
+      if (ks + 1 >= nks) break;
+      compute(1);
+      if (ks + 2 < nks) store_lds(0, ra1, rb1);
+      if (ks + 4 < nks) load_regs(ks + 4, ra1, rb1);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+      compute(ks & 1);
+      if (ks + 1 < nks) store_lds((ks + 1) & 1, ra0, rb0);
+      if (ks + 2 < nks) load_regs(ks + 2, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   // ------------------------------------------------------------------ epilogue through LDS

@@ -46,22 +46,23 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <int RW, bool GLU>
-__global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
+template <int RW, bool GLU, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
+  constexpr int NTH = NWV * 64;
   constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
   constexpr int UNR = (NR >= 4) ? 4 : (NR == 3 ? 5 : 8);  // ring depth: NR*UNR = 15..16 loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;  // [Kpad] bf16, zero padded
-  __shared__ float red[4];
-  __shared__ float sv[4];
-  __shared__ int si[4];
+  __shared__ float red[NWV];
+  __shared__ float sv[NWV];
+  __shared__ int si[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
   const int nit = Kpad >> 9;
 
   // ---- rows of this wave
-  const int rows_per_block = 4 * RW;                      // output features per workgroup
+  const int rows_per_block = NWV * RW;                    // output features per workgroup
   const int ob = blockIdx.x * rows_per_block + wave * RW; // first output feature of this wave
   const u32x4* wp[NR];
 #pragma unroll
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
   const bf16_t* xg = (const bf16_t*)a.x;
   if (a.norm_w) {
     float ss = 0.f;
-    for (int i = tid * 8; i < K; i += 256 * 8) {
+    for (int i = tid * 8; i < K; i += NTH * 8) {
       const u32x4 v = *(const u32x4*)(xg + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -104,9 +105,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
     ss = wave_sum_dpp(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
-    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) tot += red[w];
     const float rstd = rsqrtf(tot / (float)K + a.eps);
-    for (int i = tid * 8; i < Kpad; i += 256 * 8) {
+    for (int i = tid * 8; i < Kpad; i += NTH * 8) {
       u32x4 o = {0, 0, 0, 0};
       if (i < K) {
         const u32x4 v = *(const u32x4*)(xg + i);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
       *(u32x4*)(xs + i) = o;
     }
   } else {
-    for (int i = tid * 8; i < Kpad; i += 256 * 8) {
+    for (int i = tid * 8; i < Kpad; i += NTH * 8) {
       u32x4 v = {0, 0, 0, 0};
       if (i < K) v = *(const u32x4*)(xg + i);
       *(u32x4*)(xs + i) = v;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const usdm_gemv_args a) {
     if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
+      for (int w = 1; w < NWV; ++w)
         if (sv[w] > bv) { bv = sv[w]; bi = si[w]; }
       a.part_val[blockIdx.x] = bv;
       a.part_idx[blockIdx.x] = bi == 0x7fffffff ? bi : bi + a.idx_offset;
@@ -488,19 +491,34 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(!a.part_val || (a.part_idx && !glu), "usdm_gemv: part_idx missing / lm_head mode is not GLU");
   USDM_CHECK_ARG(!a.norm_w || a.K % 8 == 0, "usdm_gemv: K");
   const int nout = glu ? a.N / 2 : a.N;
-  const int rw = a.part_val ? 4 : gemv_pick_rw(nout, glu);
   const int Kpad = (a.K + 511) & ~511;
-  dim3 grid(cdiv(nout, 4 * rw)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)Kpad * 2;
+  // Wide workgroups for the mid-size projections: one workgroup per CU with 12-16 waves stages x (and the fused
+  // RMSNorm) once per 16-24 rows instead of once per 4, at the same number of loads in flight.
+  if (!glu && !a.part_val && nout % 256 == 0) {
+    const int rows_per_cu = nout / 256;
+    if (rows_per_cu == 16) {
+      hipLaunchKernelGGL((gemv_kernel<1, false, 16>), dim3(256), dim3(1024), lds, st, a);
+      USDM_LAUNCH_CHECK();
+      return 0;
+    }
+    if (rows_per_cu == 24) {
+      hipLaunchKernelGGL((gemv_kernel<2, false, 12>), dim3(256), dim3(768), lds, st, a);
+      USDM_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const int rw = a.part_val ? 4 : gemv_pick_rw(nout, glu);
+  dim3 grid(cdiv(nout, 4 * rw)), block(256);
   if (glu) {
-    if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gemv_kernel<1, true>), grid, block, lds, st, a);
+    if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, true, 4>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, true, 4>), grid, block, lds, st, a);
   } else {
-    if (rw == 4) hipLaunchKernelGGL((gemv_kernel<4, false>), grid, block, lds, st, a);
-    else if (rw == 3) hipLaunchKernelGGL((gemv_kernel<3, false>), grid, block, lds, st, a);
-    else if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, false>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gemv_kernel<1, false>), grid, block, lds, st, a);
+    if (rw == 4) hipLaunchKernelGGL((gemv_kernel<4, false, 4>), grid, block, lds, st, a);
+    else if (rw == 3) hipLaunchKernelGGL((gemv_kernel<3, false, 4>), grid, block, lds, st, a);
+    else if (rw == 2) hipLaunchKernelGGL((gemv_kernel<2, false, 4>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, false, 4>), grid, block, lds, st, a);
   }
   USDM_LAUNCH_CHECK();
   return 0;

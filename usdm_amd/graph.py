@@ -25,3 +25,32 @@ class GraphedPlan:
                 self.plan.run()
             self.graph = g
         self.graph.replay()
+
+
+class GraphedSegments:
+    """Same as GraphedPlan for a list of segments (Plans interleaved with callables such as RCCL collectives).
+    Capturing collectives into a hipGraph is attempted once; if the runtime refuses, the segments keep running
+    eagerly (still the HIP path, just launch-bound)."""
+
+    def __init__(self, segs, run_segs, enabled=None):
+        self.segs, self.run_segs = segs, run_segs
+        self.enabled = (os.environ.get("USDM_NO_GRAPH", "0") != "1" and os.environ.get("USDM_TP_GRAPH", "1") == "1") if enabled is None else enabled
+        self.graph, self.runs, self.failed = None, 0, None
+
+    def run(self):
+        self.runs += 1
+        if not self.enabled or self.runs == 1 or self.failed:
+            self.run_segs(self.segs)
+            return
+        if self.graph is None:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.run_segs(self.segs)
+                self.graph = g
+            except Exception as e:  # noqa: BLE001 - any capture failure falls back to eager launches
+                self.failed = repr(e)
+                torch.cuda.synchronize()
+                self.run_segs(self.segs)
+                return
+        self.graph.replay()

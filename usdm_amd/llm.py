@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from ._lib import ACT_SWIGLU
-from .graph import GraphedPlan
+from .graph import GraphedPlan, GraphedSegments
 
 MISTRAL_7B_USDM = dict(vocab_size=42003, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                        num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5,
@@ -321,7 +321,7 @@ class USDMForCausalLM:
         self._run_segs(segs)  # prefill + first token
         if self._decode is None:
             dsegs = self._build_decode()
-            self._decode = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else dsegs
+            self._decode = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
         eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
         produced, done, chunk = 1, False, 8
         toks = []
@@ -336,10 +336,7 @@ class USDMForCausalLM:
                 break
             n = min(chunk, max_new_tokens - produced)
             for _ in range(n):
-                if isinstance(self._decode, GraphedPlan):
-                    self._decode.run()
-                else:
-                    self._run_segs(self._decode)
+                self._decode.run()
             produced += n
         out = torch.cat([input_ids[0], torch.tensor(toks, dtype=torch.long, device=input_ids.device)])
         return out.unsqueeze(0)
