@@ -24,7 +24,7 @@ extern "C" {
 typedef void* usdm_stream_t; /* hipStream_t */
 
 enum { USDM_BF16 = 0, USDM_F32 = 1 };
-enum { USDM_ACT_NONE = 0, USDM_ACT_GELU = 1, USDM_ACT_SWIGLU = 3, USDM_ACT_TANH = 4 };
+enum { USDM_ACT_NONE = 0, USDM_ACT_GELU = 1, USDM_ACT_SWIGLU = 3, USDM_ACT_TANH = 4, USDM_ACT_LOGCLAMP = 5 /* log(max(x,1e-5)) */ };
 enum { USDM_EPI_PLAIN = 0, USDM_EPI_QKV_HEADS = 1 };
 
 const char* usdm_last_error(void);
@@ -277,6 +277,21 @@ int usdm_softmax_segments(float* x, int32_t rows, int32_t nseg, int32_t n, int32
 /* ids[t] = argmin_n(|x_t|^2 - 2*dots[t][n] + csq[n]) (first minimum); margin[t] = runner-up - best (optional) */
 int usdm_kmeans_argmin(const float* x, int32_t T, int32_t D, const float* dots, int64_t ldd, const float* csq,
                        int32_t n_units, int64_t* ids, float* margin, usdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mel front end of the speech prompt: get_mel / mel_spectrogram (util/model_util.py:24-38,
+ * vocoder/meldataset.py:55-78).  frames = Hann-windowed, reflect-padded (pad = (n_fft-hop)/2), clamped
+ * signal [T][n_fft]; the DFT is usdm_gemm(F32) against a host-built [2*nbins][n_fft] cos/-sin matrix;
+ * usdm_stft_mag = sqrt(re^2+im^2+eps); mel projection + log(clamp(.,1e-5)) = usdm_gemm with
+ * USDM_ACT_LOGCLAMP and transpose_out.  Sample-rate conversion is a polyphase FIR, also a usdm_gemm.
+ * ---------------------------------------------------------------------------------------------- */
+int usdm_stft_frames(const float* x, int32_t n, int32_t n_fft, int32_t hop, int32_t pad, const float* window,
+                     float* frames, int32_t T, usdm_stream_t stream);
+/* frames[t][c] = x[t*hop + c - offset], zero outside the signal (im2col for the polyphase resampler GEMM) */
+int usdm_frame_signal(const float* x, int32_t n, int32_t frame_len, int32_t hop, int32_t offset, float* frames, int32_t T,
+                      usdm_stream_t stream);
+int usdm_stft_mag(const float* re_im, int64_t ld, int32_t T, int32_t nbins, float eps, float* out, int64_t ldo,
+                  int32_t nbins_pad, usdm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -145,3 +145,19 @@ def test_w2v_oracle_vs_hf_wav2vec2_and_kmeans():
     ids, _ = WO.kmeans_assign(x, C)
     brute = ((x.double()[:, None] - C.double()[None]) ** 2).sum(-1).argmin(-1)
     assert torch.equal(ids, brute)
+
+
+def test_mel_oracle_sanity():
+    """librosa/torchaudio are absent (parity unpinned): check the restated pieces against their defining properties."""
+    from oracle import mel_oracle as MO
+    fb = MO.slaney_mel_filterbank(22050, 1024, 80, 0, 8000)
+    assert fb.shape == (80, 513) and (fb >= 0).all()
+    freqs = np.linspace(0, 11025, 513)
+    assert fb[:, freqs > 8000.0 + 1e-6].sum() == 0           # nothing above fmax
+    areas = (fb * (freqs[1] - freqs[0])).sum(1)
+    assert np.allclose(areas, 1.0, atol=0.06)                 # Slaney normalisation: ~unit area per filter
+    # resampler: a sine well below both Nyquists keeps its amplitude and frequency
+    t = torch.arange(16000) / 16000.0
+    y = MO.resample(torch.sin(2 * torch.pi * 440 * t), 16000, 22050)
+    t2 = torch.arange(y.numel()) / 22050.0
+    assert y.numel() == 22050 and (y[200:-200] - torch.sin(2 * torch.pi * 440 * t2)[200:-200]).abs().max() < 2e-2

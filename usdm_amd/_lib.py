@@ -22,7 +22,7 @@ lib = C.CDLL(LIB_PATH)
 lib.usdm_last_error.restype = C.c_char_p
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_TANH = 0, 1, 3, 4
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 3, 4, 5
 EPI_PLAIN, EPI_QKV_HEADS = 0, 1
 
 

@@ -196,3 +196,70 @@ extern "C" int usdm_cf_to_cl(const float* x, int32_t B, int32_t C, int32_t T, in
   return 0;
 }
 extern "C" int usdm_sizeof_snake_args(void) { return (int)sizeof(usdm_snake_args); }
+
+// ---------------------------------------------------------------------------------------------
+// Mel front end of the speech prompt (vocoder/meldataset.py:55-78): reflect padding + framing + Hann
+// window in one pass, and the magnitude sqrt(re^2 + im^2 + 1e-9) of the DFT-as-GEMM output.
+// The DFT itself (frames x [cos | -sin] matrix) and the mel projection + log run on usdm_gemm (f32 MFMA).
+namespace {
+__global__ void stft_frames_kernel(const float* __restrict__ x, int n, int n_fft, int hop, int pad, const float* __restrict__ win,
+                                   float* __restrict__ out, int T) {
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
+    int j = t * hop + i - pad;            // index into the un-padded signal
+    if (j < 0) j = -j;                    // reflect (no edge repeat), as F.pad(mode='reflect')
+    if (j > n - 1) j = 2 * (n - 1) - j;
+    float v = x[j];
+    v = fminf(fmaxf(v, -1.0f), 1.0f);     // get_mel clamps float audio to [-1, 1] (model_util.py:32)
+    out[(int64_t)t * n_fft + i] = v * win[i];
+  }
+}
+__global__ void stft_mag_kernel(const float* __restrict__ ri, int64_t ld, int nbins, float eps, float* __restrict__ out, int64_t ldo,
+                                int nbins_pad) {
+  const int t = blockIdx.x;
+  for (int k = threadIdx.x; k < nbins_pad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < nbins) {
+      const float re = ri[(int64_t)t * ld + k], im = ri[(int64_t)t * ld + nbins + k];
+      v = sqrtf((re * re + im * im) + eps);
+    }
+    out[(int64_t)t * ldo + k] = v;
+  }
+}
+}  // namespace
+
+extern "C" int usdm_stft_frames(const float* x, int32_t n, int32_t n_fft, int32_t hop, int32_t pad, const float* window,
+                                float* frames, int32_t T, usdm_stream_t stream) {
+  USDM_CHECK_ARG(x && window && frames && n > pad && T > 0, "usdm_stft_frames: bad args (signal must be longer than the reflect pad)");
+  USDM_CHECK_ARG((int64_t)(T - 1) * hop + n_fft <= (int64_t)n + 2 * pad, "usdm_stft_frames: T frames exceed the padded signal");
+  hipLaunchKernelGGL(stft_frames_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, x, n, n_fft, hop, pad, window, frames, T);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_stft_mag(const float* re_im, int64_t ld, int32_t T, int32_t nbins, float eps, float* out, int64_t ldo,
+                             int32_t nbins_pad, usdm_stream_t stream) {
+  USDM_CHECK_ARG(re_im && out && T > 0 && nbins > 0 && nbins_pad >= nbins && ld >= 2 * nbins && ldo >= nbins_pad, "usdm_stft_mag: bad args");
+  hipLaunchKernelGGL(stft_mag_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, re_im, ld, nbins, eps, out, ldo, nbins_pad);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// frames[t][c] = x[t*hop + c - offset] (zero outside [0,n)), c < frame_len : im2col of a 1-D signal for the
+// polyphase sample-rate converter (torchaudio.transforms.Resample as a GEMM).
+namespace {
+__global__ void frame_signal_kernel(const float* __restrict__ x, int n, int frame_len, int hop, int offset, float* __restrict__ out, int T) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < frame_len; c += blockDim.x) {
+    const int64_t j = (int64_t)t * hop + c - offset;
+    out[(int64_t)t * frame_len + c] = (j >= 0 && j < n) ? x[j] : 0.f;
+  }
+}
+}  // namespace
+extern "C" int usdm_frame_signal(const float* x, int32_t n, int32_t frame_len, int32_t hop, int32_t offset, float* frames, int32_t T,
+                                 usdm_stream_t stream) {
+  USDM_CHECK_ARG(x && frames && n > 0 && frame_len > 0 && hop > 0 && T > 0, "usdm_frame_signal: bad args");
+  hipLaunchKernelGGL(frame_signal_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, x, n, frame_len, hop, offset, frames, T);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
     if (rbf) x = round_bf(x);
     if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
     else if (a.act == USDM_ACT_TANH) x = tanhf(x);
+    else if (a.act == USDM_ACT_LOGCLAMP) x = logf(fmaxf(x, 1e-5f));
     return x;
   };
 

@@ -284,3 +284,21 @@ def kmeans_argmin(x, dots, csq, ids, *, T, D, n_units, ldd, margin=None, plan=No
     _need_cuda(x, dots, csq, ids, margin)
     _go(plan, "usdm_kmeans_argmin", lib.usdm_kmeans_argmin, _ptr(x), C_.c_int32(T), C_.c_int32(D), _ptr(dots), C_.c_int64(ldd),
         _ptr(csq), C_.c_int32(n_units), _ptr(ids), _ptr(margin))
+
+
+def stft_frames(x, window, frames, *, n, n_fft, hop, pad, T, plan=None):
+    _need_cuda(x, window, frames)
+    _go(plan, "usdm_stft_frames", lib.usdm_stft_frames, _ptr(x), C_.c_int32(n), C_.c_int32(n_fft), C_.c_int32(hop), C_.c_int32(pad),
+        _ptr(window), _ptr(frames), C_.c_int32(T))
+
+
+def stft_mag(re_im, out, *, ld, T, nbins, eps, ldo, nbins_pad, plan=None):
+    _need_cuda(re_im, out)
+    _go(plan, "usdm_stft_mag", lib.usdm_stft_mag, _ptr(re_im), C_.c_int64(ld), C_.c_int32(T), C_.c_int32(nbins), C_.c_float(eps),
+        _ptr(out), C_.c_int64(ldo), C_.c_int32(nbins_pad))
+
+
+def frame_signal(x, frames, *, n, frame_len, hop, offset, T, plan=None):
+    _need_cuda(x, frames)
+    _go(plan, "usdm_frame_signal", lib.usdm_frame_signal, _ptr(x), C_.c_int32(n), C_.c_int32(frame_len), C_.c_int32(hop),
+        C_.c_int32(offset), _ptr(frames), C_.c_int32(T))

@@ -13,15 +13,39 @@ import torch
 
 from ... import ops
 from ..model import Voicebox
+from ..vocoder.meldataset import mel_spectrogram, resample
 from ..vocoder.models import BigVGAN
 
 mel_mean = -5.5419
 mel_std = 2.1575
 
 
-def get_mel(filepath, length=None, hps=None):
-    raise NotImplementedError("get_mel (torchaudio load + Resample + mel_spectrogram, model_util.py:24-38) is the "
-                              "'next' row of SURVEY.md §8(f); pass reference_mel= to reconstruct_speech")
+def load_wav_to_torch(full_path):
+    """util/train_util.py:36-38 (torchaudio.load) with scipy: mono float waveform in [-1, 1] + sample rate (host I/O)."""
+    import numpy as np
+    from scipy.io.wavfile import read
+    sr, data = read(full_path)
+    x = data.astype(np.float32)
+    if data.dtype == np.int16:
+        x /= 32768.0
+    elif data.dtype == np.int32:
+        x /= 2147483648.0
+    if x.ndim == 2:
+        x = x[:, 0]
+    return torch.from_numpy(x), sr
+
+
+def get_mel(filepath, length=None, hps=None, device="cuda"):
+    """wav file -> log-mel [1, num_mels, frames] on the GPU (model_util.py:24-38)."""
+    audio, sr = load_wav_to_torch(filepath)
+    audio = audio.to(device)
+    if sr != hps.sampling_rate:
+        audio = resample(audio, sr, hps.sampling_rate)
+    if length:
+        audio = audio[:length]
+    # clamp(-1, 1) of float audio happens inside the framing kernel
+    return mel_spectrogram(audio.unsqueeze(0), hps.n_fft, hps.num_mels, hps.sampling_rate, hps.hop_size, hps.win_size, hps.fmin,
+                           hps.fmax, center=False)
 
 
 def process_unit(unit, hps, device):
@@ -49,7 +73,12 @@ def reconstruct_speech(agent_unit, device, reference_path, token_extractor, voic
     token_extractor.predict) and `reference_mel` ([1, 80, frames] log-mel, un-normalised)."""
     agent_unit, _ = process_unit(agent_unit, vocoder.h, device)
     if reference_path is not None and reference_mel is None:
-        raise NotImplementedError("decoding reference_path needs get_mel (SURVEY.md §8f 'next'); pass reference_mel/reference_unit")
+        # reference prompt from a wav file, as the reference does (model_util.py:76-82); file decode + 16 kHz resampling are host I/O
+        from ...inference import load_audio_16k
+        ref16 = torch.as_tensor(load_audio_16k(reference_path), dtype=torch.float32).to(device)
+        reference_unit = token_extractor.predict(ref16, 35 - 1)
+        _, new_length = process_unit(reference_unit, vocoder.h, device)
+        reference_mel = get_mel(reference_path, new_length, vocoder.h, device=device)
     if reference_mel is not None:
         if reference_unit is None:
             raise ValueError("reference_unit (50 Hz ids of the prompt) is required with reference_mel")
