@@ -356,36 +356,47 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     ((bf16_t*)a.kcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
     ((bf16_t*)a.vcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
   }
-  // ---- scores: 8 lanes per key, 16 d each
+  // ---- scores: 8 lanes per key, 16 d each; the K rows of SW sweeps are requested before any of them is used
   {
+    constexpr int SW = 4;
     const int j = lane & 7, gk = (wave << 3) + (lane >> 3);  // key slot within a 32-key sweep
     float qr[G][16];
 #pragma unroll
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 16; ++e) qr[h][e] = qs[h][j * 16 + e];
-    for (int kk = gk; kk < nk; kk += 32) {
-      const int ki = k0 + kk;
-      float kv[16];
-      if (ki == pos) {
+    for (int base = 0; base < nk; base += 32 * SW) {
+      u32x4 r0[SW], r1[SW];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) kv[e] = knew[j * 16 + e];
-      } else {
-        const u32x4 r0 = *(const u32x4*)(Kc + (int64_t)ki * 128 + j * 16);
-        const u32x4 r1 = *(const u32x4*)(Kc + (int64_t)ki * 128 + j * 16 + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          kv[2 * e] = bf2f(r0[e] & 0xffff); kv[2 * e + 1] = bf2f(r0[e] >> 16);
-          kv[8 + 2 * e] = bf2f(r1[e] & 0xffff); kv[8 + 2 * e + 1] = bf2f(r1[e] >> 16);
-        }
+      for (int w = 0; w < SW; ++w) {
+        const int kk = min(base + 32 * w + gk, nk - 1);
+        const bf16_t* kp = Kc + (int64_t)(k0 + kk) * 128 + j * 16;
+        r0[w] = *(const u32x4*)kp;
+        r1[w] = *(const u32x4*)(kp + 8);
       }
 #pragma unroll
-      for (int h = 0; h < G; ++h) {
-        float s = 0.f;
+      for (int w = 0; w < SW; ++w) {
+        const int kk = base + 32 * w + gk;
+        if (kk >= nk) continue;
+        const bool is_new = (k0 + kk) == pos;     // the new token's K is not in the cache yet: take it from LDS
+        float kv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s = fmaf(qr[h][e], kv[e], s);
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if (j == 0) sc[h][kk] = s * a.scale;
+        for (int e = 0; e < 4; ++e) {
+          kv[2 * e] = bf2f(r0[w][e] & 0xffff); kv[2 * e + 1] = bf2f(r0[w][e] >> 16);
+          kv[8 + 2 * e] = bf2f(r1[w][e] & 0xffff); kv[8 + 2 * e + 1] = bf2f(r1[w][e] >> 16);
+        }
+        if (is_new) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) kv[e] = knew[j * 16 + e];
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sdot = fmaf(qr[h][e], kv[e], sdot);
+          sdot += __shfl_xor(sdot, 1, 64); sdot += __shfl_xor(sdot, 2, 64); sdot += __shfl_xor(sdot, 4, 64);
+          if (j == 0) sc[h][kk] = sdot * a.scale;
+        }
       }
     }
   }
@@ -413,21 +424,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
-    for (int kk = kl; kk < nk; kk += 8) {
-      const int ki = k0 + kk;
-      float v[4];
-      if (ki == pos) {
+    constexpr int PW = 4;   // V rows requested together
+    for (int base = 0; base < nk; base += 8 * PW) {
+      u32x2 rv[PW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = vnew[d4 + e];
-      } else {
-        const u32x2 r = *(const u32x2*)(Vc + (int64_t)ki * 128 + d4);
-        v[0] = bf2f(r[0] & 0xffff); v[1] = bf2f(r[0] >> 16); v[2] = bf2f(r[1] & 0xffff); v[3] = bf2f(r[1] >> 16);
+      for (int w = 0; w < PW; ++w) {
+        const int kk = min(base + 8 * w + kl, nk - 1);
+        rv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
       }
 #pragma unroll
-      for (int h = 0; h < G; ++h) {
-        const float p = sc[h][kk];
+      for (int w = 0; w < PW; ++w) {
+        const int kk = base + 8 * w + kl;
+        if (kk >= nk) continue;
+        float v[4] = {bf2f(rv[w][0] & 0xffff), bf2f(rv[w][0] >> 16), bf2f(rv[w][1] & 0xffff), bf2f(rv[w][1] >> 16)};
+        if (k0 + kk == pos) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
+          for (int e = 0; e < 4; ++e) v[e] = vnew[d4 + e];
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          const float p = sc[h][kk];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
+        }
       }
     }
 #pragma unroll
