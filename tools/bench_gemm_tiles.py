@@ -1,5 +1,6 @@
 import os, sys, subprocess
-for t in (0, 1, 2):
-    print("== tile", ["128x128", "128x64", "64x64"][t], flush=True)
+names = ["128x128/4w", "128x64/4w", "64x64/4w", "128x128/8w"]
+for t in ([int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]):
+    print("== tile", names[t], flush=True)
     env = dict(os.environ, USDM_GEMM_TILE=str(t))
     subprocess.run([sys.executable, "tools/bench_gemm.py"], env=env)

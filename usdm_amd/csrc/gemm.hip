@@ -48,14 +48,17 @@ __device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
   return (g / (1.0f + __expf(-g))) * u;
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
+template <typename T, int BM, int BN, int NWM, int NWN>   // NWM x NWN waves over the BM x BN tile
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const usdm_gemm_args& a = g.a;
+  constexpr int NTH = NWM * NWN * 64;
+  constexpr int WTM = BM / NWM, WTN = BN / NWN;  // wave tile
   constexpr int ES = sizeof(T);       // element size
   constexpr int CE = 64 / ES;         // elements per chunk
   constexpr int PE = 16 / ES;         // elements per 16-B piece
-  constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 MFMA tiles per wave
-  constexpr int LA = BM / 32, LB = BN / 32;  // 16-B loads per thread per K-step
+  constexpr int TM = WTM / 16, TN = WTN / 16;  // 16x16 MFMA tiles per wave
+  constexpr int LA = BM * 8 / NTH, LB = BN * 8 / NTH;  // 16-B loads per thread per K-step
+  constexpr int RSTEP = NTH / 8;      // rows covered by one load pass
   constexpr int STAGE = (BM + BN) * 128;     // bytes per LDS stage
   constexpr int CST = BN + 4;                // f32 row stride of the epilogue tile (bank-conflict-free)
   constexpr int EPI = BM * CST * 4;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 15, lc = lane >> 4;
 
   // tile mapping: blocks that share an XCD (blockIdx % 8) get consecutive tiles; N is walked first
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
     const int roff = a.a_row_off + tap * a.a_row_step;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int m = m0 + r0 + 32 * i;
+      const int m = m0 + r0 + RSTEP * i;
       const int row = m * a.a_row_mul + roff;
       const bool v = qv && ((unsigned)row < (unsigned)a.rowsA);
       const unsigned off = v ? ((unsigned)row * lda_b + colA) : OOB;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int n = n0 + r0 + 32 * i;
+      const int n = n0 + r0 + RSTEP * i;
       const bool v = qv && (n < a.N);
       const unsigned off = v ? ((unsigned)n * ldw_b + colW) : OOB;
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
@@ -124,12 +127,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
     char* sB = sA + BM * 128;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int r = r0 + 32 * i;
+      const int r = r0 + RSTEP * i;
       *(u32x4*)(sA + sub * (BM * 64) + r * 64 + ((pc ^ swz(r)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int r = r0 + 32 * i;
+      const int r = r0 + RSTEP * i;
       *(u32x4*)(sB + sub * (BN * 64) + r * 64 + ((pc ^ swz(r)) << 4)) = rb[i];
     }
   };
@@ -145,12 +148,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
       u32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / 2) + i * 16 + lr;
+        const int r = wm * WTM + i * 16 + lr;
         fa[i] = *(const u32x4*)(sA + s * (BM * 64) + r * 64 + ((lc ^ swz(r)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int r = wn * (BN / 2) + j * 16 + lr;
+        const int r = wn * WTN + j * 16 + lr;
         fb[j] = *(const u32x4*)(sB + s * (BN * 64) + r * 64 + ((lc ^ swz(r)) << 4));
       }
       static_for<TM>([&](auto I) {
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   // software pipeline: LDS stage (ks & 1) is multiplied while step ks+1 is written to the other stage.
   // Small tiles (cheap in registers, short MFMA phase) keep TWO K-steps of loads in flight in two register
   // sets; the 128x128 tile keeps one (a second set would halve its occupancy: measured slower).
-  constexpr bool PF2 = (BM * BN <= 128 * 64);
+  constexpr bool PF2 = (BM * BN <= 128 * 64) || (NTH > 256);
   load_regs(0, ra0, rb0);
   store_lds(0, ra0, rb0);
   if (nks > 1) load_regs(1, ra0, rb0);
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   float* ct = (float*)smem;  // [BM][CST] f32
   static_for<TM>([&](auto I) {
     static_for<TN>([&](auto J) {
-      const int col = wn * (BN / 2) + J * 16 + lr;
-      const int row = wm * (BM / 2) + I * 16 + lc * 4;
+      const int col = wn * WTN + J * 16 + lr;
+      const int row = wm * WTM + I * 16 + lc * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ct[(row + e) * CST + col] = acc[I][J][e];
     });
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   if (a.act == USDM_ACT_SWIGLU) {
     // column tiles (2p, 2p+1) of 16 hold gate / up of the same 16 output features
     constexpr int OC = BN / 2;  // output columns of this tile
-    for (int idx = tid; idx < BM * (OC / 4); idx += 256) {
+    for (int idx = tid; idx < BM * (OC / 4); idx += NTH) {
       const int r = idx / (OC / 4), c4 = (idx - r * (OC / 4)) * 4;
       const int m = m0 + r;
       const int cg = (c4 >> 4) * 32 + (c4 & 15);   // gate column inside the tile
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   // ---- pass 1: outputs whose fast axis is n (row-major C, Q and K of the head-split epilogue)
   if (!col_major_out) {
     const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
-    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+    for (int idx = tid; idx < BM * (BN / 4); idx += NTH) {
       const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
       const int m = m0 + r, n = n0 + c4;
       if (m >= a.M || n >= a.N) continue;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
     if (!is_qkv) return;
   }
   // ---- pass 2: outputs whose fast axis is m (transpose_out, V^T of the head-split epilogue)
-  for (int idx = tid; idx < BN * (BM / 4); idx += 256) {
+  for (int idx = tid; idx < BN * (BM / 4); idx += NTH) {
     const int c = idx / (BM / 4), r4 = (idx - c * (BM / 4)) * 4;
     const int n = n0 + c, m = m0 + r4;
     if (n >= a.N || m >= a.M) continue;
@@ -347,14 +350,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev g) {
   }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NWM = 2, int NWN = 2>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
   GemmDev g;
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN>), grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
 }
@@ -407,10 +410,12 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else sel = 2;
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
   if (a.dtype == USDM_BF16) {
+    if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
   } else {
+    if (sel == 3) return launch<float, 128, 128, 2, 4>(a, st);
     if (sel == 0) return launch<float, 128, 128>(a, st);
     if (sel == 1) return launch<float, 128, 64>(a, st);
     return launch<float, 64, 64>(a, st);
