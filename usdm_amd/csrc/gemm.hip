@@ -48,7 +48,7 @@ __device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
   return (g / (1.0f + __expf(-g))) * u;
 }
 
-template <typename T, int BM, int BN, int NWM, int NWN>   // NWM x NWN waves over the BM x BN tile
+template <typename T, int BM, int BN, int NWM, int NWN, bool DMA>   // NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const usdm_gemm_args& a = g.a;
   constexpr int NTH = NWM * NWN * 64;
@@ -140,6 +140,44 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
 
+  // ---- LDS-DMA loader (buffer_load_dwordx4 ... lds): a wave-instruction fills 64 consecutive 16-B slots of the LDS
+  // image = 16 rows x 4 pieces of one sub-chunk plane; the XOR swizzle is applied on the SOURCE side (slot c' of row r
+  // receives logical piece c' ^ swz(r)), out-of-range rows/chunks are redirected past the descriptor (zeros).
+  auto dma_issue = [&](int stage, int ks) {
+    constexpr int QA = BM / 16 * 2, QB = BN / 16 * 2;      // wave-instructions per operand per K-step
+    constexpr int NWV = NWM * NWN;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    char* sAst = smem + stage * STAGE;
+    char* sBst = sAst + BM * 128;
+    const int lrow = lane >> 2, lp = lane & 3;
+#pragma unroll
+    for (int i = 0; i < (QA + NWV - 1) / NWV; ++i) {
+      const int qi = wv + NWV * i;
+      if (QA % NWV != 0 && qi >= QA) break;
+      const int sb = qi / (BM / 16), rg = qi - sb * (BM / 16);
+      const int r = rg * 16 + lrow;
+      const int q = 2 * ks + sb;
+      const int tap = q / cpt;
+      const int cb = (q - tap * cpt) * CE + (lp ^ swz(r)) * PE;
+      const int row = (m0 + r) * a.a_row_mul + a.a_row_off + tap * a.a_row_step;
+      const bool v = (q < Q) && ((unsigned)row < (unsigned)a.rowsA);
+      const unsigned off = v ? ((unsigned)row * lda_b + (unsigned)((cb + (int64_t)tap * a.a_tap_stride) * ES)) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAst + qi * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < (QB + NWV - 1) / NWV; ++i) {
+      const int qi = wv + NWV * i;
+      if (QB % NWV != 0 && qi >= QB) break;
+      const int sb = qi / (BN / 16), rg = qi - sb * (BN / 16);
+      const int r = rg * 16 + lrow;
+      const int q = 2 * ks + sb;
+      const int n = n0 + r;
+      const bool v = (q < Q) && (n < a.N);
+      const unsigned off = v ? ((unsigned)n * ldw_b + (unsigned)((q * CE + (lp ^ swz(r)) * PE) * ES)) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBst + qi * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
   auto compute = [&](int stage) {
     const char* sA = smem + stage * STAGE;
     const char* sB = sA + BM * 128;
@@ -178,6 +216,18 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // Small tiles (cheap in registers, short MFMA phase) keep TWO K-steps of loads in flight in two register
   // sets; the 128x128 tile keeps one (a second set would halve its occupancy: measured slower).
   constexpr bool PF2 = (BM * BN <= 128 * 64) || (NTH > 256);
+  if constexpr (DMA) {
+    // two LDS stages; step ks+1 streams into the idle stage by LDS-DMA while step ks is multiplied
+    dma_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) dma_issue((ks + 1) & 1, ks + 1);
+      compute(ks & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   load_regs(0, ra0, rb0);
   store_lds(0, ra0, rb0);
   if (nks > 1) load_regs(1, ra0, rb0);
@@ -203,6 +253,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       if (ks + 2 < nks) load_regs(ks + 2, ra0, rb0);
       __syncthreads();
     }
+  }
   }
 
   // ------------------------------------------------------------------ epilogue through LDS
@@ -350,14 +401,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   }
 }
 
-template <typename T, int BM, int BN, int NWM = 2, int NWN = 2>
+template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
   GemmDev g;
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN>), grid, dim3(NWM * NWN * 64), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
 }
@@ -411,11 +462,17 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
+    if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);
+    if (sel == 5) return launch<bf16_t, 64, 64, 2, 2, true>(a, st);
+    if (sel == 6) return launch<bf16_t, 128, 64, 2, 2, true>(a, st);
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
   } else {
     if (sel == 3) return launch<float, 128, 128, 2, 4>(a, st);
+    if (sel == 4) return launch<float, 128, 128, 2, 2, true>(a, st);
+    if (sel == 5) return launch<float, 64, 64, 2, 2, true>(a, st);
+    if (sel == 6) return launch<float, 128, 64, 2, 2, true>(a, st);
     if (sel == 0) return launch<float, 128, 128>(a, st);
     if (sel == 1) return launch<float, 128, 64>(a, st);
     return launch<float, 64, 64>(a, st);
