@@ -97,6 +97,11 @@ def test_attn_decode(dev, ctx):
     ops.attn_decode(qkv.to(dev), torch.tensor([pos], dtype=torch.int32, device=dev), cos.to(dev), sin.to(dev), kcd, vcd,
                     pm, pl, po, out, Hq=Hq, Hkv=Hkv, ctx_max=ctx_max, NS=NS, scale=d ** -0.5)
     assert (out.cpu().double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    # single-workgroup-per-kv-head form (NS = 1)
+    out1 = torch.zeros_like(out)
+    ops.attn_decode(qkv.to(dev), torch.tensor([pos], dtype=torch.int32, device=dev), cos.to(dev), sin.to(dev), kc.to(dev), vc.to(dev),
+                    pm, pl, po, out1, Hq=Hq, Hkv=Hkv, ctx_max=ctx_max, NS=1, scale=d ** -0.5)
+    assert (out1.cpu().double() - ref).abs().max() <= 2e-2 * ref.abs().max()
     # the new K/V row was appended
     assert torch.equal(kcd[:, pos].cpu(), kr) and torch.equal(vcd[:, pos].cpu(), v)
 

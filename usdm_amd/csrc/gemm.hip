@@ -143,42 +143,73 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // ---- LDS-DMA loader (buffer_load_dwordx4 ... lds): a wave-instruction fills 64 consecutive 16-B slots of the LDS
   // image = 16 rows x 4 pieces of one sub-chunk plane; the XOR swizzle is applied on the SOURCE side (slot c' of row r
   // receives logical piece c' ^ swz(r)), out-of-range rows/chunks are redirected past the descriptor (zeros).
-  auto dma_issue = [&](int stage, int ks) {
-    constexpr int QA = BM / 16 * 2, QB = BN / 16 * 2;      // wave-instructions per operand per K-step
-    constexpr int NWV = NWM * NWN;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    char* sAst = smem + stage * STAGE;
-    char* sBst = sAst + BM * 128;
+  // Per-lane offsets of the wave-instructions this wave issues are loop invariants: only the chunk column
+  // (+64 B per chunk) and, for multi-tap operands, the row shift change from K-step to K-step.
+  constexpr int QA = BM / 16 * 2, QB = BN / 16 * 2;      // wave-instructions per operand per K-step
+  constexpr int NWV = NWM * NWN;
+  constexpr int NIA = (QA + NWV - 1) / NWV, NIB = (QB + NWV - 1) / NWV;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const bool simple = (a.taps == 1);                     // Linear layers: no per-tap row remap
+  unsigned dofA[NIA], dofB[NIB];                         // byte offset of (row, swizzled piece) at chunk 0; >= 2^31 if the row is out of range
+  int drA[NIA];                                          // tile row of the A instruction (multi-tap path)
+  if constexpr (DMA) {
     const int lrow = lane >> 2, lp = lane & 3;
 #pragma unroll
-    for (int i = 0; i < (QA + NWV - 1) / NWV; ++i) {
+    for (int i = 0; i < NIA; ++i) {
       const int qi = wv + NWV * i;
-      if (QA % NWV != 0 && qi >= QA) break;
       const int sb = qi / (BM / 16), rg = qi - sb * (BM / 16);
       const int r = rg * 16 + lrow;
+      drA[i] = r;
+      const int row = (m0 + r) * a.a_row_mul + a.a_row_off;
+      const bool v = (unsigned)row < (unsigned)a.rowsA;
+      dofA[i] = (v ? (unsigned)row * lda_b : 0xC0000000u) + (unsigned)(((lp ^ swz(r)) * PE + sb * CE) * ES);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int qi = wv + NWV * i;
+      const int sb = qi / (BN / 16), rg = qi - sb * (BN / 16);
+      const int r = rg * 16 + lrow;
+      const bool v = (n0 + r) < a.N;
+      dofB[i] = (v ? (unsigned)(n0 + r) * ldw_b : 0xC0000000u) + (unsigned)(((lp ^ swz(r)) * PE + sb * CE) * ES);
+    }
+  }
+  // issue the wave-instructions [i0, i1) of operand A and [j0, j1) of operand W for K-step ks into `stage`
+  auto dma_issue = [&](int stage, int ks, int i0, int i1, int j0, int j1) {
+    char* sAst = smem + stage * STAGE;
+    char* sBst = sAst + BM * 128;
+    const unsigned kcol = (unsigned)(2 * ks * 64);       // 2 chunks of 64 B per K-step
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      if (i < i0 || i >= i1) continue;
+      const int qi = wv + NWV * i;
+      if (QA % NWV != 0 && qi >= QA) break;
+      const int sb = qi / (BM / 16);
       const int q = 2 * ks + sb;
-      const int tap = q / cpt;
-      const int cb = (q - tap * cpt) * CE + (lp ^ swz(r)) * PE;
-      const int row = (m0 + r) * a.a_row_mul + a.a_row_off + tap * a.a_row_step;
-      const bool v = (q < Q) && ((unsigned)row < (unsigned)a.rowsA);
-      const unsigned off = v ? ((unsigned)row * lda_b + (unsigned)((cb + (int64_t)tap * a.a_tap_stride) * ES)) : OOB;
+      unsigned off;
+      if (simple) {
+        off = (q < Q) ? dofA[i] + kcol : OOB;
+      } else {
+        const int lp = lane & 3, r = drA[i];
+        const int tap = q / cpt;
+        const int cb = (q - tap * cpt) * CE + (lp ^ swz(r)) * PE;
+        const int row = (m0 + r) * a.a_row_mul + a.a_row_off + tap * a.a_row_step;
+        const bool v = (q < Q) && ((unsigned)row < (unsigned)a.rowsA);
+        off = v ? ((unsigned)row * lda_b + (unsigned)((cb + (int64_t)tap * a.a_tap_stride) * ES)) : OOB;
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAst + qi * 1024), 16, off, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < (QB + NWV - 1) / NWV; ++i) {
+    for (int i = 0; i < NIB; ++i) {
+      if (i < j0 || i >= j1) continue;
       const int qi = wv + NWV * i;
       if (QB % NWV != 0 && qi >= QB) break;
-      const int sb = qi / (BN / 16), rg = qi - sb * (BN / 16);
-      const int r = rg * 16 + lrow;
-      const int q = 2 * ks + sb;
-      const int n = n0 + r;
-      const bool v = (q < Q) && (n < a.N);
-      const unsigned off = v ? ((unsigned)n * ldw_b + (unsigned)((q * CE + (lp ^ swz(r)) * PE) * ES)) : OOB;
+      const int sb = qi / (BN / 16);
+      const unsigned off = (2 * ks + sb < Q) ? dofB[i] + kcol : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBst + qi * 1024), 16, off, 0, 0, 0);
     }
   };
 
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, auto&& between) {
     const char* sA = smem + stage * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
@@ -209,6 +240,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           }
         });
       });
+      if (s == 0) between();
     }
   };
 
@@ -218,12 +250,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr bool PF2 = (BM * BN <= 128 * 64) || (NTH > 256);
   if constexpr (DMA) {
     // two LDS stages; step ks+1 streams into the idle stage by LDS-DMA while step ks is multiplied
-    dma_issue(0, 0);
+    dma_issue(0, 0, 0, NIA, 0, NIB);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
-      if (ks + 1 < nks) dma_issue((ks + 1) & 1, ks + 1);
-      compute(ks & 1);
+      // the next step's DMA is issued in two halves, one before each sub-chunk's MFMA cluster
+      const bool more = ks + 1 < nks;
+      if (more) dma_issue((ks + 1) & 1, ks + 1, 0, (NIA + 1) / 2, 0, (NIB + 1) / 2);
+      compute(ks & 1, [&]() { if (more) dma_issue((ks + 1) & 1, ks + 1, (NIA + 1) / 2, NIA, (NIB + 1) / 2, NIB); });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -235,12 +269,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     if (nks > 2) load_regs(2, ra1, rb1);
     __syncthreads();
     for (int ks = 0; ks < nks; ks += 2) {
-      compute(0);
+      compute(0, []() {});
       if (ks + 1 < nks) store_lds(1, ra0, rb0);
       if (ks + 3 < nks) load_regs(ks + 3, ra0, rb0);
       __syncthreads();
       if (ks + 1 >= nks) break;
-      compute(1);
+      compute(1, []() {});
       if (ks + 2 < nks) store_lds(0, ra1, rb1);
       if (ks + 4 < nks) load_regs(ks + 4, ra1, rb1);
       __syncthreads();
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   } else {
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
-      compute(ks & 1);
+      compute(ks & 1, []() {});
       if (ks + 1 < nks) store_lds((ks + 1) & 1, ra0, rb0);
       if (ks + 2 < nks) load_regs(ks + 2, ra0, rb0);
       __syncthreads();
@@ -454,9 +488,14 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t z = (int64_t)a.groups * a.batch;
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
-  int sel;  // 0: 128x128, 1: 128x64, 2: 64x64
+  int sel;  // 4: 128x128, 6: 128x64, 5: 64x64 (LDS-DMA variants); 0-3: register-staged variants kept for A/B runs
+  // 128x128 wins when its tiles fill one round (2 workgroups per CU) or many rounds; in between, wave quantisation
+  // makes the small tile faster (profiles/r01_gemm_tiles.txt).
+  // In-situ measurements (tools/stage_times.py, profiles/r01_gemm_ablation.txt): with operands coming from HBM/MALL
+  // rather than a hot L2, the register-staged loaders (two K-steps in flight) beat the single-stage LDS-DMA loaders on
+  // the mid-size shapes of the path; the DMA variant is used where it wins clearly: large single-tap GEMMs.
   if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
-  else if (t128 >= 640) sel = 0;
+  else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override

@@ -469,6 +469,155 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode attention, one 16-wave workgroup per kv head (no context split, no partials, no combine launch):
+// at batch 1 the phase is latency-bound, not bandwidth-bound (<= ~0.8 MB of K/V per kv head), so the fastest form is
+// the one with the fewest dependent steps: rope q/k -> scores (16 waves x 8 keys per sweep) -> softmax (wave per head)
+// -> PV (32 key lanes x 32 d-quads) -> in-LDS reduction -> bf16 output.  Same numerics as the split version.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(1024) void attn_decode1_kernel(const usdm_attn_decode_args a) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  float* sc = (float*)dsm;                          // [G][ctx_pad]
+  const int pos = *a.pos;
+  const int ctx = pos + 1;
+  const int ctx_pad = (a.ctx_max + 3) & ~3;
+  float* red = sc + G * ctx_pad;                    // [16][G][128]
+  __shared__ float qs[G][128];
+  __shared__ float knew[128], vnew[128];
+  __shared__ float lsum[G], lmax[G];
+  const int kh = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  for (int i = tid; i < (G + 1) * 64; i += 1024) {
+    const int hsel = i >> 6, d = i & 63;
+    const float c = bf2f(a.cos[(int64_t)pos * 64 + d]), sn = bf2f(a.sin[(int64_t)pos * 64 + d]);
+    const bf16_t* src = hsel < G ? qkv + (kh * G + hsel) * 128 : qkv + (a.Hq + kh) * 128;
+    float o1, o2;
+    rope_pair(bf2f(src[d]), bf2f(src[d + 64]), c, sn, o1, o2);
+    if (hsel < G) { qs[hsel][d] = o1; qs[hsel][d + 64] = o2; }
+    else { knew[d] = o1; knew[d + 64] = o2; }
+  }
+  if (tid >= 512 && tid < 640) vnew[tid - 512] = bf2f(qkv[(a.Hq + a.Hkv + kh) * 128 + tid - 512]);
+  __syncthreads();
+  const bf16_t* Kc = (const bf16_t*)a.kcache + (int64_t)kh * a.ctx_max * 128;
+  const bf16_t* Vc = (const bf16_t*)a.vcache + (int64_t)kh * a.ctx_max * 128;
+  if (tid < 128) {
+    ((bf16_t*)a.kcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
+    ((bf16_t*)a.vcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
+  }
+  // ---- scores
+  {
+    constexpr int SW = 2;
+    const int j = lane & 7, gk = (wave << 3) + (lane >> 3);   // 128 keys per block sweep
+    float qr[G][16];
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) qr[h][e] = qs[h][j * 16 + e];
+    for (int base = 0; base < ctx; base += 128 * SW) {
+      u32x4 r0[SW], r1[SW];
+#pragma unroll
+      for (int w = 0; w < SW; ++w) {
+        const int kk = min(base + 128 * w + gk, ctx - 1);
+        const bf16_t* kp = Kc + (int64_t)kk * 128 + j * 16;
+        r0[w] = *(const u32x4*)kp;
+        r1[w] = *(const u32x4*)(kp + 8);
+      }
+#pragma unroll
+      for (int w = 0; w < SW; ++w) {
+        const int kk = base + 128 * w + gk;
+        if (kk >= ctx) continue;
+        float kv[16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kv[2 * e] = bf2f(r0[w][e] & 0xffff); kv[2 * e + 1] = bf2f(r0[w][e] >> 16);
+          kv[8 + 2 * e] = bf2f(r1[w][e] & 0xffff); kv[8 + 2 * e + 1] = bf2f(r1[w][e] >> 16);
+        }
+        if (kk == pos) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) kv[e] = knew[j * 16 + e];
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sdot = fmaf(qr[h][e], kv[e], sdot);
+          sdot += __shfl_xor(sdot, 1, 64); sdot += __shfl_xor(sdot, 2, 64); sdot += __shfl_xor(sdot, 4, 64);
+          if (j == 0) sc[h * ctx_pad + kk] = sdot * a.scale;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax statistics: wave h <-> head h
+  if (wave < G) {
+    const int h = wave;
+    float m = -1e30f;
+    for (int kk = lane; kk < ctx; kk += 64) m = fmaxf(m, sc[h * ctx_pad + kk]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int kk = lane; kk < ctx; kk += 64) {
+      const float p = __expf(sc[h * ctx_pad + kk] - m);
+      l += p;
+      sc[h * ctx_pad + kk] = round_bf(p);
+    }
+    l = wave_sum(l);
+    if (lane == 0) { lsum[h] = l; lmax[h] = m; }
+  }
+  __syncthreads();
+  // ---- PV: 32 key lanes x 32 d-quads; lanes l and l^32 of a wave share the d-quad
+  {
+    constexpr int PW = 4;
+    const int d4 = (tid & 31) * 4, kl = tid >> 5;   // kl in [0, 32)
+    float acc[G][4];
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
+    for (int base = 0; base < ctx; base += 32 * PW) {
+      u32x2 rv[PW];
+#pragma unroll
+      for (int w = 0; w < PW; ++w) {
+        const int kk = min(base + 32 * w + kl, ctx - 1);
+        rv[w] = *(const u32x2*)(Vc + (int64_t)kk * 128 + d4);
+      }
+#pragma unroll
+      for (int w = 0; w < PW; ++w) {
+        const int kk = base + 32 * w + kl;
+        if (kk >= ctx) continue;
+        float v[4] = {bf2f(rv[w][0] & 0xffff), bf2f(rv[w][0] >> 16), bf2f(rv[w][1] & 0xffff), bf2f(rv[w][1] >> 16)};
+        if (kk == pos) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = vnew[d4 + e];
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          const float p = sc[h * ctx_pad + kk];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[h][e];
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 32) red[(wave * G + h) * 128 + d4 + e] = v;
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < G * 128; i += 1024) {
+    const int h = i >> 7, d = i & 127;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[(w * G + h) * 128 + d];
+    ((bf16_t*)a.out)[(kh * G + h) * 128 + d] = f2bf(s / lsum[h]);
+  }
+}
+
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out) {
   __shared__ float w[64];
   __shared__ float linv;
@@ -578,13 +727,32 @@ extern "C" int usdm_rope_cache(const usdm_rope_args* pa, usdm_stream_t stream) {
 }
 
 extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t stream) {
-  USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && pa->pm && pa->pl && pa->po && pa->out, "usdm_attn_decode: null args");
+  USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && pa->out, "usdm_attn_decode: null args");
+  USDM_CHECK_ARG(pa->NS == 1 || (pa->pm && pa->pl && pa->po), "usdm_attn_decode: partial buffers missing");
   const usdm_attn_decode_args& a = *pa;
   USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0 && a.NS <= 64, "usdm_attn_decode: heads / NS (<= 64)");
-  USDM_CHECK_ARG(cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
+  USDM_CHECK_ARG(a.NS == 1 || cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
   const int G = a.Hq / a.Hkv;
-  dim3 grid(a.Hkv, a.NS);
   hipStream_t st = (hipStream_t)stream;
+  if (a.NS == 1) {   // single-workgroup-per-kv-head form: no partials, no combine
+    const int ctx_pad = (a.ctx_max + 3) & ~3;
+    const size_t lds = (size_t)(G * ctx_pad + 16 * G * 128) * sizeof(float);
+    USDM_CHECK_ARG(lds <= 120 * 1024, "usdm_attn_decode: ctx_max too large for the one-workgroup form (use NS > 1)");
+    static bool attr_set = false;
+    if (!attr_set) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup)
+      (void)hipFuncSetAttribute((const void*)attn_decode1_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_decode1_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_decode1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      attr_set = true;
+    }
+    if (G == 4) hipLaunchKernelGGL(attn_decode1_kernel<4>, dim3(a.Hkv), dim3(1024), lds, st, a);
+    else if (G == 2) hipLaunchKernelGGL(attn_decode1_kernel<2>, dim3(a.Hkv), dim3(1024), lds, st, a);
+    else if (G == 1) hipLaunchKernelGGL(attn_decode1_kernel<1>, dim3(a.Hkv), dim3(1024), lds, st, a);
+    else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
+  dim3 grid(a.Hkv, a.NS);
   if (G == 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, st, a);
   else if (G == 2) hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), 0, st, a);
   else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);

@@ -60,7 +60,7 @@ def shard_weights(sd_get, cfg, rank, tp, device, dtype=torch.bfloat16):
 
 
 class USDMForCausalLM:
-    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=16, tp_segments=None):
+    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=None, tp_segments=None):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -83,7 +83,11 @@ class USDMForCausalLM:
         self.v0 = min(V, tp_rank * self.Vloc)
         self.v1 = min(V, self.v0 + self.Vloc)
         self.ctx_max = (ctx_max + 63) // 64 * 64
-        self.NS = decode_splits
+        import os
+        # decode attention: 1 = one 16-wave workgroup per kv head (no partials / combine launch); >1 = context split
+        self.NS = int(os.environ.get("USDM_DECODE_SPLITS", "32")) if decode_splits is None else decode_splits
+        if self.NS == 1 and self.ctx_max > 4096:
+            self.NS = 16
         self.W = None
         self._prefill_plans = {}
         self._decode = None
