@@ -48,16 +48,30 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
-// ---- wave64 reductions --------------------------------------------------------------------------
+// ---- wave64 all-reductions without LDS traffic: DPP inside 16-lane rows, v_permlane{16,32}_swap across rows ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

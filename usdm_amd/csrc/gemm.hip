@@ -413,9 +413,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       const int HD = a.qkv_H * a.qkv_D;
       if (n < 2 * HD) continue;
       const int hn = n - 2 * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-      for (int e = 0; e < mv; ++e) {
-        const int mm = m + e, b = mm / a.qkv_S, s = mm - b * a.qkv_S;
-        ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s] = f2bf(v[e]);
+      const int b0 = m / a.qkv_S, s0 = m - b0 * a.qkv_S;
+      bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
+      if (mv == 4 && s0 + 3 < a.qkv_S && (s0 & 1) == 0) {        // 4 tokens of one sequence: two packed 4-byte stores
+        *(unsigned*)(vrow + s0) = pack_bf2(v[0], v[1]);
+        *(unsigned*)(vrow + s0 + 2) = pack_bf2(v[2], v[3]);
+      } else {
+        for (int e = 0; e < mv; ++e) {
+          const int mm = m + e, b = mm / a.qkv_S, s = mm - b * a.qkv_S;
+          ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s] = f2bf(v[e]);
+        }
       }
       continue;
     }

@@ -30,23 +30,6 @@ __device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
 //     ring is issued BEFORE x is staged / RMS-normalised into LDS, so the prologue hides under HBM latency;
 //   * RW is chosen by the launcher so that the grid is a whole number of workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_xadd(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-  return v + __int_as_float(t);
-}
-// wave64 all-reduce sum without LDS traffic: DPP inside 16-lane rows, v_permlane{16,32}_swap across rows
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v = dpp_xadd<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_xadd<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_xadd<0x141>(v);  // row_half_mirror
-  v = dpp_xadd<0x140>(v);  // row_mirror
-  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 template <int RW, bool GLU, int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
@@ -103,7 +86,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
         ss += lo * lo + hi * hi;
       }
     }
-    ss = wave_sum_dpp(ss);
+    ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     float tot = 0.f;
@@ -152,7 +135,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     }
   }
 #pragma unroll
-  for (int j = 0; j < NR; ++j) acc[j] = wave_sum_dpp(acc[j]);
+  for (int j = 0; j < NR; ++j) acc[j] = wave_sum(acc[j]);
 
   // ---- epilogue
   if (a.part_val) {  // lm_head: bf16-rounded logits, ban mask, per-block arg-max (ties -> lowest id)
