@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--nt", type=int, default=64, help="Voicebox n_timesteps (Heun halves it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vocoder-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: run the multi-rank code path (process group, collectives, TP plan segments) on however many ranks there are")
     return ap.parse_args()
 
 
@@ -50,7 +52,8 @@ class Pipeline:
         self.dev, self.rank, self.world, self.args = dev, rank, world, args
         t0 = time.time()
         self.ue = synth.make_unit_extractor(dev)
-        self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group)
+        self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group,
+                                  tp_segments=True if (args.force_dist or world > 1) else None)
         self.vb = synth.make_voicebox(dev)
         self.voc = synth.make_bigvgan(dev, compute_dtype=torch.float32 if args.vocoder_dtype == "f32" else torch.bfloat16)
         torch.cuda.synchronize()
@@ -236,15 +239,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -261,7 +266,7 @@ def main():
             stage_acc = pipe.ev
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,9 +296,9 @@ def main():
         res["roofline"] = measure_gemv_roofline(pipe.llm)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
-    elif world > 1:
+    elif dist_on:
         measure_gemv_roofline(pipe.llm)  # collectives inside the TP decode need every rank
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -20,9 +20,13 @@ class GraphedPlan:
             self.plan.run()
             return
         if self.graph is None:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.plan.run()
+            # capture outside inference mode: the RNG bookkeeping tensors torch registers at the first capture must
+            # not become inference tensors (callers such as reconstruct_speech run under @torch.inference_mode()),
+            # or a later capture outside inference mode fails with "Inplace update to inference tensor"
+            with torch.inference_mode(False):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.plan.run()
             self.graph = g
         self.graph.replay()
 
@@ -46,9 +50,10 @@ class GraphedSegments:
             return
         if self.graph is None:
             try:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.run_segs(self.segs)
+                with torch.inference_mode(False):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.run_segs(self.segs)
                 self.graph = g
             except Exception as e:  # noqa: BLE001 - any capture failure falls back to eager launches
                 self.failed = repr(e)
