@@ -174,10 +174,12 @@ def test_tp_code_path_single_rank_nccl(dev):
         b = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128, tp_segments=True, group=dist.group.WORLD).generate(
             input_ids=ids, max_new_tokens=12)
         assert torch.equal(a, b)
-        os.environ["USDM_TP_GRAPH"] = "1"   # opt-in hipGraph capture of the collectives
+        os.environ["USDM_TP_GRAPH"] = "0"   # eager collectives
+        m0 = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128, tp_segments=True, group=dist.group.WORLD)
+        assert torch.equal(a, m0.generate(input_ids=ids, max_new_tokens=12)) and m0._decode.graph is None
+        os.environ.pop("USDM_TP_GRAPH")
         m = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128, tp_segments=True, group=dist.group.WORLD)
         c = m.generate(input_ids=ids, max_new_tokens=12)
-        os.environ.pop("USDM_TP_GRAPH")
         print("TP decode graph captured:", m._decode.graph is not None, "fallback reason:", m._decode.failed)
         assert torch.equal(a, c)
     finally:

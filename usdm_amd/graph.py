@@ -38,9 +38,11 @@ class GraphedSegments:
 
     def __init__(self, segs, run_segs, enabled=None):
         self.segs, self.run_segs = segs, run_segs
-        # opt-in (USDM_TP_GRAPH=1): capturing RCCL collectives into a hipGraph was only verified on a 1-rank group
-        # (no multi-GPU box was available to this round); the default keeps collectives eager, which cannot hang a capture
-        self.enabled = (os.environ.get("USDM_NO_GRAPH", "0") != "1" and os.environ.get("USDM_TP_GRAPH", "0") == "1") if enabled is None else enabled
+        # Collectives are captured with the kernels (torch's ProcessGroupNCCL supports stream capture; verified here on a
+        # 1-rank RCCL group, the only kind a one-GPU box can form).  Eager TP is host-bound (~65 collectives + ~200
+        # launches per token), so the graph is the default; USDM_TP_GRAPH=0 forces eager, and any capture error falls
+        # back to eager launches.
+        self.enabled = (os.environ.get("USDM_NO_GRAPH", "0") != "1" and os.environ.get("USDM_TP_GRAPH", "1") == "1") if enabled is None else enabled
         self.graph, self.runs, self.failed = None, 0, None
 
     def run(self):
