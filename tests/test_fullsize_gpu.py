@@ -103,3 +103,43 @@ def test_config4_voicebox_full_width_one_heun_step_plus_bigvgan(dev):
     snr = 10 * torch.log10(wav_ref.pow(2).sum() / (wav - wav_ref).pow(2).sum()).item()
     print("config 4 bigvgan (full width, 40 frames) SNR dB", snr)
     assert snr >= 50.0
+
+
+def test_bigvgan_full_size_locality_property(dev):
+    """BASELINE full size (861 frames -> 220 416 samples), size-independent property: the generator is a finite-receptive-
+    field conv net, so the waveform of a mel prefix equals the prefix of the full waveform away from the cut."""
+    from usdm_amd import synth
+    voc = synth.make_bigvgan(dev)
+    mel = (torch.randn(1, 80, 861, generator=torch.Generator().manual_seed(5)) * 2.1575 - 5.5419).to(dev)
+    full = voc(mel).clone()
+    assert full.shape == (1, 1, 861 * 256) and torch.isfinite(full).all()
+    part = voc(mel[:, :, :400].contiguous())
+    keep = (400 - 40) * 256     # 40 frames of margin >> receptive field of the 6-stage dilated stack in mel frames
+    err = (full[0, 0, :keep] - part[0, 0, :keep]).abs().max().item()
+    print("bigvgan prefix property max diff", err)
+    assert err <= 1e-4
+    assert (full[0, 0, keep:400 * 256] - part[0, 0, keep:]).abs().max().item() > 0   # the cut region does differ
+
+
+def test_llm_decode_path_equals_prefill_path_full_width(dev):
+    """KV-cache consistency at the 7B widths (4 layers): the logits the GEMV/decode-attention path produces after feeding
+    tokens one by one equal the logits of the MFMA prefill path on the same sequence, within bf16 noise."""
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    cfg = dict(MO.MISTRAL_7B_USDM, num_hidden_layers=4)
+    m = USDMForCausalLM.random_init(cfg, dev, seed=8, ctx_max=256)
+    m.keep_logits = True
+    ids = torch.randint(3, 42000, (1, 40), generator=torch.Generator().manual_seed(9)).to(dev)
+    out = m.generate(input_ids=ids, max_new_tokens=9)          # prefill 40, then 8 decode steps
+    dec_logits = m.last_logits.clone()                         # logits that chose token 40+9
+    m2 = USDMForCausalLM(cfg, dev, ctx_max=256)
+    m2.W = m.W
+    m2._alloc()
+    m2.keep_logits = True
+    m2.generate(input_ids=out[:, :-1], max_new_tokens=1)       # prefill of the first 48 tokens -> logits for token 49
+    pre_logits = m2.last_logits
+    err = (dec_logits - pre_logits).abs().max().item()
+    scale = pre_logits.abs().max().item()
+    print("decode-vs-prefill logits max diff", err, "scale", scale)
+    assert err <= 4e-2 * scale
+    assert int(dec_logits.argmax()) == int(out[0, -1]) or err > 0
