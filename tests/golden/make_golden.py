@@ -154,6 +154,19 @@ def make_bigvgan():
         save(name, seed=seed, c0=c0, mel=mel, wav=wav)
 
 
+def make_bigvgan_variant():
+    """resblock '2' (AMPBlock2) + 'snake' activation: the other generator configuration the reference supports."""
+    g = torch.Generator().manual_seed(201)
+    h = dict(BO.BIGVGAN_22K_80, upsample_initial_channel=64, resblock="2", activation="snake",
+             resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
+    sd = BO.random_state_dict(h, seed=23)
+    m = ref_bigvgan(h, sd)
+    mel = torch.randn(1, 80, 10, generator=g) * 2.1575 - 5.5419
+    with torch.no_grad():
+        wav = m(mel)
+    save("bigvgan_amp2_snake.npz", seed=23, c0=64, mel=mel, wav=wav)
+
+
 def make_process_unit():
     from voicebox.util.model_util import process_unit
     from voicebox.vocoder.env import AttrDict
@@ -174,6 +187,10 @@ def make_process_unit():
 
 
 if __name__ == "__main__":
+    if "--only-variant" in sys.argv:
+        make_bigvgan_variant()
+        sys.exit(0)
     make_process_unit()
+    make_bigvgan_variant()
     make_bigvgan()
     make_voicebox()

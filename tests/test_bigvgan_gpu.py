@@ -70,3 +70,20 @@ def test_bigvgan_rejects_cpu():
     m = BigVGAN(AttrDict(dict(BO.BIGVGAN_22K_80, upsample_initial_channel=64)))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 80, 4))
+
+
+def test_bigvgan_amp2_snake_variant_golden(dev):
+    """The other generator configuration the reference supports (models.py:153, 88-128; activations.py:9-59)."""
+    from oracle import bigvgan_oracle as BO
+    from usdm_amd.voicebox.vocoder.env import AttrDict
+    from usdm_amd.voicebox.vocoder.models import BigVGAN
+    d = np.load(os.path.join(G, "bigvgan_amp2_snake.npz"))
+    h = AttrDict(dict(BO.BIGVGAN_22K_80, upsample_initial_channel=64, resblock="2", activation="snake",
+                      resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]]))
+    m = BigVGAN(h)
+    m.remove_weight_norm()
+    res = m.load_state_dict(BO.random_state_dict(h, int(d["seed"])), strict=False)
+    assert not res.unexpected_keys and all(k.endswith("filter") for k in res.missing_keys)
+    wav = m.to(dev).eval()(torch.from_numpy(d["mel"]).to(dev)).cpu()
+    ref = torch.from_numpy(d["wav"])
+    assert _snr(wav, ref) >= 50.0 and (wav - ref).abs().max().item() <= 2e-3

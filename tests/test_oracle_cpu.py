@@ -37,6 +37,9 @@ def test_bigvgan_small_and_full():
         assert wav.shape == d["wav"].shape
         _close(wav, d["wav"], 1e-5)
         assert d["wav"].abs().mean() > 0.05  # fixture is not degenerate
+    d = _load("bigvgan_amp2_snake.npz")   # AMPBlock2 + Snake variant
+    h = dict(BO.BIGVGAN_22K_80, upsample_initial_channel=64, resblock="2", activation="snake", resblock_dilation_sizes=[[1, 3]] * 3)
+    _close(BO.bigvgan_forward(BO.random_state_dict(h, seed=int(d["seed"])), h, d["mel"]), d["wav"], 1e-5)
 
 
 def test_voicebox_small():

@@ -80,6 +80,32 @@ class SnakeBeta(nn.Module):
         self.beta = nn.Parameter(init.clone() * alpha)
 
 
+class Snake(nn.Module):
+    """Parameter holder for activations.Snake (reference: vocoder/activations.py:9-59): x + sin^2(x a)/(a + 1e-9)."""
+
+    def __init__(self, in_features, alpha=1.0, alpha_trainable=True, alpha_logscale=False):
+        super().__init__()
+        self.in_features = in_features
+        self.alpha_logscale = alpha_logscale
+        init = torch.zeros(in_features) if alpha_logscale else torch.ones(in_features)
+        self.alpha = nn.Parameter(init.clone() * alpha)
+
+
+def _make_act(name, channels, logscale):
+    if name == "snakebeta":
+        return SnakeBeta(channels, alpha_logscale=logscale)
+    if name == "snake":
+        return Snake(channels, alpha_logscale=logscale)
+    raise NotImplementedError("activation incorrectly specified. check the config file and look for 'activation'.")
+
+
+def _act_params(act, dev):
+    """(alpha, beta) device tensors for usdm_aa_snake; Snake is SnakeBeta with beta = alpha."""
+    a = act.alpha.detach().float().to(dev).contiguous()
+    b = act.beta.detach().float().to(dev).contiguous() if hasattr(act, "beta") else a
+    return a, b
+
+
 class Activation1d(nn.Module):
     """Parameter holder for alias_free_torch.act.Activation1d (2x up, SnakeBeta, 2x down, 12 taps)."""
 
@@ -106,14 +132,30 @@ class AMPBlock1(nn.Module):
             weight_norm(nn.Conv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1)))
             for _ in dilation])
         self.num_layers = len(self.convs1) + len(self.convs2)
-        if activation != "snakebeta":
-            raise NotImplementedError("activation incorrectly specified. check the config file and look for 'activation'. "
-                                      "(the MI355X path implements 'snakebeta', the bigvgan_22khz_80band setting)")
         self.activations = nn.ModuleList([
-            Activation1d(activation=SnakeBeta(channels, alpha_logscale=h.snake_logscale)) for _ in range(self.num_layers)])
+            Activation1d(activation=_make_act(activation, channels, h.snake_logscale)) for _ in range(self.num_layers)])
 
     def remove_weight_norm(self):
         for l in list(self.convs1) + list(self.convs2):
+            remove_weight_norm(l)
+
+
+class AMPBlock2(nn.Module):
+    """Parameter holder for AMPBlock2 (reference: vocoder/models.py:88-128): x = x + conv_d(act(x)) per dilation."""
+
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3), activation=None):
+        super().__init__()
+        self.h = h
+        self.kernel_size, self.dilation = kernel_size, tuple(dilation)
+        self.convs = nn.ModuleList([
+            weight_norm(nn.Conv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
+            for d in dilation])
+        self.num_layers = len(self.convs)
+        self.activations = nn.ModuleList([
+            Activation1d(activation=_make_act(activation, channels, h.snake_logscale)) for _ in range(self.num_layers)])
+
+    def remove_weight_norm(self):
+        for l in self.convs:
             remove_weight_norm(l)
 
 
@@ -170,8 +212,7 @@ class BigVGAN(nn.Module):
         self.num_kernels = len(h.resblock_kernel_sizes)
         self.num_upsamples = len(h.upsample_rates)
         self.conv_pre = weight_norm(nn.Conv1d(h.num_mels, h.upsample_initial_channel, 7, 1, padding=3))
-        if h.resblock != "1":
-            raise NotImplementedError("the MI355X path implements AMPBlock1 (resblock '1'), the bigvgan_22khz_80band setting")
+        resblock = AMPBlock1 if h.resblock == "1" else AMPBlock2
         self.ups = nn.ModuleList()
         for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
             self.ups.append(nn.ModuleList([weight_norm(nn.ConvTranspose1d(
@@ -181,10 +222,8 @@ class BigVGAN(nn.Module):
         for i in range(len(self.ups)):
             ch = h.upsample_initial_channel // (2 ** (i + 1))
             for k, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
-                self.resblocks.append(AMPBlock1(h, ch, k, d, activation=h.activation))
-        if h.activation != "snakebeta":
-            raise NotImplementedError("activation incorrectly specified. check the config file and look for 'activation'.")
-        self.activation_post = Activation1d(activation=SnakeBeta(ch, alpha_logscale=h.snake_logscale))
+                self.resblocks.append(resblock(h, ch, k, d, activation=h.activation))
+        self.activation_post = Activation1d(activation=_make_act(h.activation, ch, h.snake_logscale))
         self.conv_post = weight_norm(nn.Conv1d(ch, 1, 7, 1, padding=3))
         for m in list(self.ups.modules()) + [self.conv_post]:
             if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
@@ -256,16 +295,17 @@ class BigVGAN(nn.Module):
                 blk = self.resblocks[i * self.num_kernels + j]
                 layers = []
                 for l, d in enumerate(blk.dilation):
-                    a1, a2 = blk.activations[2 * l].act, blk.activations[2 * l + 1].act
-                    layers.append(dict(
-                        w1=_pack_conv(_folded_weight(blk.convs1[l]).to(dev), cp, cd), b1=blk.convs1[l].bias.detach().float().to(dev).contiguous(),
-                        w2=_pack_conv(_folded_weight(blk.convs2[l]).to(dev), cp, cd), b2=blk.convs2[l].bias.detach().float().to(dev).contiguous(),
-                        a1=(a1.alpha.detach().float().to(dev).contiguous(), a1.beta.detach().float().to(dev).contiguous()),
-                        a2=(a2.alpha.detach().float().to(dev).contiguous(), a2.beta.detach().float().to(dev).contiguous()),
-                        d=d))
-                P["blocks"].append(dict(k=blk.kernel_size, layers=layers))
-        ap = self.activation_post.act
-        P["post_a"] = (ap.alpha.detach().float().to(dev).contiguous(), ap.beta.detach().float().to(dev).contiguous())
+                    if isinstance(blk, AMPBlock1):
+                        layers.append(dict(
+                            w1=_pack_conv(_folded_weight(blk.convs1[l]).to(dev), cp, cd), b1=blk.convs1[l].bias.detach().float().to(dev).contiguous(),
+                            w2=_pack_conv(_folded_weight(blk.convs2[l]).to(dev), cp, cd), b2=blk.convs2[l].bias.detach().float().to(dev).contiguous(),
+                            a1=_act_params(blk.activations[2 * l].act, dev), a2=_act_params(blk.activations[2 * l + 1].act, dev), d=d))
+                    else:
+                        layers.append(dict(
+                            w1=_pack_conv(_folded_weight(blk.convs[l]).to(dev), cp, cd), b1=blk.convs[l].bias.detach().float().to(dev).contiguous(),
+                            a1=_act_params(blk.activations[l].act, dev), d=d))
+                P["blocks"].append(dict(k=blk.kernel_size, layers=layers, two=isinstance(blk, AMPBlock1)))
+        P["post_a"] = _act_params(self.activation_post.act, dev)
         P["post_w"] = _pack_conv(_folded_weight(self.conv_post).to(dev), _pad32(ch), cd)
         P["post_b"] = self.conv_post.bias.detach().float().to(dev).contiguous()
         P["logscale"] = bool(h.snake_logscale)
@@ -307,6 +347,11 @@ class BigVGAN(nn.Module):
                 for lay in blk["layers"]:
                     d = lay["d"]
                     ops.aa_snake(src, lay["a1"][0], lay["a1"][1], taps, taps_dn, T=Tn, C=cp, Creal=cout, logscale=ls, plan=plan, **ok(a16))
+                    if not blk["two"]:   # AMPBlock2: x = x + conv_d(act(x))
+                        ops.gemm(a16, lay["w1"], M=Tn, N=cout, Kc=cp, taps=k, rowsA=Tn, a_row_off=-get_padding(k, d), a_row_step=d,
+                                 bias=lay["b1"], residual=src, ldr=cp, out32=y32, ldc=cp, plan=plan)
+                        src = y32
+                        continue
                     ops.gemm(a16, lay["w1"], M=Tn, N=cout, Kc=cp, taps=k, rowsA=Tn, a_row_off=-get_padding(k, d), a_row_step=d,
                              bias=lay["b1"], out32=xt32, ldc=cp, plan=plan)
                     ops.aa_snake(xt32, lay["a2"][0], lay["a2"][1], taps, taps_dn, T=Tn, C=cp, Creal=cout, logscale=ls, plan=plan, **ok(a16))
