@@ -186,6 +186,11 @@ typedef struct usdm_vb_solver_args {
 } usdm_vb_solver_args;
 int usdm_vb_solver_step(const usdm_vb_solver_args* args, usdm_stream_t stream);
 
+/* Padding mask of ragged Voicebox batches (networks.py:330-333 and the `* y_mask` products): zero every time step
+ * t >= valid_len[b] - off of x; layout 0 = [B][T][C] (channels-last), 1 = [B][C][T] (channels-first). */
+int usdm_mask_time(float* x32, void* x16_bf16, int32_t B, int32_t T, int32_t C, int32_t layout, const int32_t* valid_len,
+                   int32_t off, usdm_stream_t stream);
+
 /* device-to-device async copy (graph-capturable plumbing) */
 int usdm_copy_bytes(void* dst, const void* src, int64_t nbytes, usdm_stream_t stream);
 

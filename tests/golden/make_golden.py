@@ -116,6 +116,24 @@ def make_voicebox():
     save("voicebox_full.npz", seed=12, x=xx, y=y, cond=cond, t=0.61, est=est)
 
 
+def make_voicebox_ragged():
+    """Batch of 2 with different lengths: the padding masks of networks.py:314-341 and the `* y_mask` products.
+    (estimator only: CFM.sample views the scalar t as [B,1,1], so the reference's generate() is batch-1, voicebox.py:52)"""
+    g = torch.Generator().manual_seed(101)
+    cfg = SMALL_VB
+    sd = VO.random_state_dict(cfg, seed=13)
+    m = ref_voicebox(cfg, sd)
+    S = 52
+    lengths = torch.tensor([52, 33])
+    x = torch.randint(0, cfg["n_tokens"], (2, S), generator=g)
+    y = torch.randn(2, 80, S, generator=g)
+    cond = torch.randn(2, 80, S, generator=g)
+    t = torch.tensor([0.3, 0.8]).view(2, 1, 1)
+    with torch.no_grad():
+        est = m.estimator(x, y, cond, t, lengths)
+    save("voicebox_ragged.npz", seed=13, x=x, y=y, cond=cond, t=t, lengths=lengths, est=est)
+
+
 def ref_bigvgan(h, sd):
     from voicebox.vocoder.env import AttrDict
     from voicebox.vocoder.models import BigVGAN
@@ -190,7 +208,11 @@ if __name__ == "__main__":
     if "--only-variant" in sys.argv:
         make_bigvgan_variant()
         sys.exit(0)
+    if "--only-ragged" in sys.argv:
+        make_voicebox_ragged()
+        sys.exit(0)
     make_process_unit()
     make_bigvgan_variant()
     make_bigvgan()
     make_voicebox()
+    make_voicebox_ragged()

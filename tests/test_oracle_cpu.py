@@ -58,6 +58,15 @@ def test_voicebox_small():
     _close(gen, d["gen_e"], 1e-4)
 
 
+def test_voicebox_ragged_batch():
+    from tests.golden.configs import SMALL_VB
+    d = _load("voicebox_ragged.npz")
+    sd = VO.random_state_dict(SMALL_VB, seed=int(d["seed"]))
+    est = VO.estimator_forward(sd, SMALL_VB, d["x"], d["y"], d["cond"], d["t"], d["lengths"])
+    _close(est, d["est"], 2e-5)
+    assert est[1, :, int(d["lengths"][1]):].abs().max() == 0
+
+
 def test_voicebox_full_width():
     d = _load("voicebox_full.npz")
     cfg = VO.VOICEBOX_CFG

@@ -77,5 +77,20 @@ def test_voicebox_rejects_cpu_and_ragged(dev):
     x = torch.zeros(1, 8, dtype=torch.long)
     with pytest.raises(RuntimeError):
         m.generate(x, torch.zeros(1, 80, 8), torch.tensor([8]), 2)
-    with pytest.raises(NotImplementedError):
-        m.generate(x.to(dev), torch.zeros(1, 80, 8, device=dev), torch.tensor([5]).to(dev), 2)
+    with pytest.raises(ValueError):
+        m.generate(x.to(dev), torch.zeros(1, 80, 8, device=dev), torch.tensor([9]).to(dev), 2)   # length > frames
+
+
+def test_voicebox_ragged_batch_estimator(dev):
+    """Batch of 2 with lengths [52, 33]: padding masks (networks.py:314-341 and the `* y_mask` products) vs the reference."""
+    from tests.golden.configs import SMALL_VB
+    d = _ld("voicebox_ragged.npz")
+    m = _model(SMALL_VB, int(d["seed"]), dev)
+    est = m.estimator(d["x"].to(dev), d["y"].to(dev), d["cond"].to(dev), d["t"].to(dev), d["lengths"].to(dev))
+    r = _rel(est, d["est"])
+    print("ragged estimator rel L2", r)
+    assert r <= 1e-2
+    assert est[1, :, 33:].abs().max().item() == 0.0      # padded frames are exactly zero, as in the reference
+    # a full-length call right after re-uses a different (non-ragged) plan
+    full = m.estimator(d["x"].to(dev), d["y"].to(dev), d["cond"].to(dev), d["t"].to(dev), torch.tensor([52, 52]).to(dev))
+    assert full[1, :, 33:].abs().max().item() > 0

@@ -143,3 +143,30 @@ extern "C" int usdm_process_unit(const int64_t* units, int32_t n, int32_t rep, i
   USDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Padding mask of ragged batches (networks.py:330-333 `hidden_states[~mask] = 0`, the `* y_mask` of :94,:257-266,:370-372):
+// zero every time step t >= valid_len[b] - off of x, for rows-major [B][T][C] (layout 0) or channels-first [B][C][T] (1).
+namespace {
+__global__ void mask_time_kernel(float* x32, bf16_t* x16, int B, int T, int C, int layout, const int* valid_len, int off) {
+  const int64_t n = (int64_t)B * T * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int b, t;
+    if (layout == 0) { const int64_t r = i / C; b = (int)(r / T); t = (int)(r - (int64_t)b * T); }
+    else { b = (int)(i / ((int64_t)C * T)); t = (int)(i % T); }
+    if (t >= valid_len[b] - off) {
+      if (x32) x32[i] = 0.f;
+      if (x16) x16[i] = 0;
+    }
+  }
+}
+}  // namespace
+extern "C" int usdm_mask_time(float* x32, void* x16, int32_t B, int32_t T, int32_t C, int32_t layout, const int32_t* valid_len,
+                              int32_t off, usdm_stream_t stream) {
+  USDM_CHECK_ARG((x32 || x16) && valid_len && B > 0 && T > 0 && C > 0 && (layout == 0 || layout == 1), "usdm_mask_time: bad args");
+  const int64_t n = (int64_t)B * T * C;
+  hipLaunchKernelGGL(mask_time_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x32, (bf16_t*)x16, B, T, C, layout, valid_len, off);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -302,3 +302,9 @@ def frame_signal(x, frames, *, n, frame_len, hop, offset, T, plan=None):
     _need_cuda(x, frames)
     _go(plan, "usdm_frame_signal", lib.usdm_frame_signal, _ptr(x), C_.c_int32(n), C_.c_int32(frame_len), C_.c_int32(hop),
         C_.c_int32(offset), _ptr(frames), C_.c_int32(T))
+
+
+def mask_time(valid_len, *, B, T, C, layout, off=0, x32=None, x16=None, plan=None):
+    _need_cuda(valid_len, x32, x16)
+    _go(plan, "usdm_mask_time", lib.usdm_mask_time, _ptr(x32), _ptr(x16), C_.c_int32(B), C_.c_int32(T), C_.c_int32(C),
+        C_.c_int32(layout), _ptr(valid_len), C_.c_int32(off))

@@ -163,7 +163,7 @@ class Transformer(nn.Module):
         return P
 
     # ------------------------------------------------------------------ plan
-    def build_plan(self, B_in, S1, dup, use_cond, dev):
+    def build_plan(self, B_in, S1, dup, use_cond, dev, ragged=False):
         """Pre-built launch sequence for one estimator evaluation at batch B_in*dup, S1 frames."""
         if self._packed is None:
             self._packed = self._pack(dev)
@@ -191,6 +191,9 @@ class Transformer(nn.Module):
         ops.vb_time_token(io["t"], P["freqs"], h32, cur, Bx=Bx, H=H, rows_per_batch=S, plan=plan)
         ops.gemm(ain, P["w_in"], M=S1, N=H, Kc=P["kinp"], lda=P["kinp"], rowsA=S1, batch=Bx, a_bstride=S1 * P["kinp"],
                  c_bstride=S, c_row_off=1, bias=P["b_in"], out32=h32, out16=cur, ldc=H, plan=plan)
+        vl = io["kv_len"]   # lengths + 1 (time token), per batch row of the (possibly CFG-doubled) batch
+        if ragged:          # hidden_states[~mask] = 0 (networks.py:330-333)
+            ops.mask_time(vl, B=Bx, T=S, C=H, layout=0, x32=h32, x16=cur, plan=plan)
         G, kw = self.convpos_groups, self.convpos_width
         cg = H // G
         src = cur
@@ -199,10 +202,13 @@ class Transformer(nn.Module):
             ops.gemm(src, w, M=S, N=cg, Kc=cg, taps=kw, lda=H, rowsA=S, a_row_off=-(kw // 2), a_row_step=1, groups=G, batch=Bx,
                      a_gstride=cg, w_gstride=cg * kw * cg, a_bstride=S * H, c_gcol=cg, c_bstride=S, bias=b, act=ACT_GELU,
                      out32=tmp32 if last else None, out16=None if last else pc16, ldc=H, plan=plan)
+            if ragged and not last:   # `hidden_states * y_mask` between the positional convolutions (networks.py:94)
+                ops.mask_time(vl, B=Bx, T=S, C=H, layout=0, x16=pc16, plan=plan)
             src = pc16
         # h = LN(posconv + residual): skip stack bottom is this output
         slot = 2
-        ops.norm(tmp32, *P["ln0"], rows=R, C=H, res=h32, out32=h32, out16=arena[slot], plan=plan)
+        mk = dict(valid_len=vl, rows_per_batch=S) if ragged else {}
+        ops.norm(tmp32, *P["ln0"], rows=R, C=H, res=h32, out32=h32, out16=arena[slot], plan=plan, **mk)
         cur = arena[slot]
         stack = [slot]
         slot += 1
@@ -216,10 +222,10 @@ class Transformer(nn.Module):
                           v_strides=(nh * 64 * Spad, 64 * Spad, Spad), o_strides=(S * H, H), scale=1.0,
                           kv_len=io["kv_len"], slopes=slopes, alibi_col0_zero=True, plan=plan)
             ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=tmp32, plan=plan)
-            ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan)
+            ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan, **mk)
             ops.gemm(pc16, lp["w1"], M=R, N=I, Kc=H, bias=lp["b1"], act=ACT_GELU, out16=f16, plan=plan)
             ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=tmp32, plan=plan)
-            ops.norm(tmp32, *lp["ln2"], rows=R, C=H, out32=h32, out16=out16, plan=plan)
+            ops.norm(tmp32, *lp["ln2"], rows=R, C=H, out32=h32, out16=out16, plan=plan, **mk)
 
         for n in range(L):
             lp = P["layers"][n]
@@ -243,12 +249,14 @@ class Transformer(nn.Module):
         # proj_out over rows 1..S of each batch, stored transposed as [Bx][F][S1]
         ops.gemm(cur[1:], P["w_out"], M=S1, N=F_, Kc=H, lda=H, rowsA=S1, batch=Bx, a_bstride=S * H, c_bstride=F_ * S1,
                  bias=P["b_out"], out32=io["out"], ldc=S1, transpose_out=True, plan=plan)
+        if ragged:          # `proj_out(h) * y_mask`, token 0 dropped (networks.py:372-374)
+            ops.mask_time(vl, B=Bx, T=S1, C=F_, layout=1, off=1, x32=io["out"], plan=plan)
         return plan, io
 
-    def get_plan(self, B_in, S1, dup, use_cond, dev):
-        key = (B_in, S1, dup, bool(use_cond), dev.index)
+    def get_plan(self, B_in, S1, dup, use_cond, dev, ragged=False):
+        key = (B_in, S1, dup, bool(use_cond), dev.index, bool(ragged))
         if key not in self._plans:
-            plan, io = self.build_plan(B_in, S1, dup, use_cond, dev)
+            plan, io = self.build_plan(B_in, S1, dup, use_cond, dev, ragged)
             self._plans[key] = (GraphedPlan(plan), io)
         return self._plans[key]
 
@@ -259,9 +267,12 @@ class Transformer(nn.Module):
         if not y.is_cuda:
             raise RuntimeError("Voicebox estimator (usdm_amd) runs on the MI355X only; there is no CPU fallback")
         B, _, S1 = y.shape
-        if not bool((lengths.to("cpu") == S1).all()):
-            raise NotImplementedError("ragged batches (lengths < frames) are not implemented on the HIP path yet")
-        gp, io = self.get_plan(B, S1, 1, True, y.device)
+        lens = lengths.to("cpu")
+        if bool((lens > S1).any()) or bool((lens < 0).any()):
+            raise ValueError("lengths must lie in [0, frames]")
+        ragged = not bool((lens == S1).all())
+        gp, io = self.get_plan(B, S1, 1, True, y.device, ragged)
+        io["kv_len"].copy_((lengths + 1).to(torch.int32))
         io["ids"].copy_(x)
         io["y"].copy_(y)
         io["cond"].copy_(cond)

@@ -43,8 +43,10 @@ class CFM(BaseModule):
             raise RuntimeError("Voicebox.generate (usdm_amd) runs on the MI355X only; there is no CPU fallback")
         dev = cond.device
         B, F_, S = cond.shape
-        if not bool((cond_lengths.to("cpu") == S).all()):
-            raise NotImplementedError("ragged batches (lengths < frames) are not implemented on the HIP path yet")
+        lens = cond_lengths.to("cpu")
+        if bool((lens > S).any()) or bool((lens < 0).any()):
+            raise ValueError("cond_lengths must lie in [0, frames]")
+        ragged = not bool((lens == S).all())
         heun = solver == "heun"
         n = (n_timesteps + 1) // 2 if heun else n_timesteps
         P = int(prompt_lengths[0]) if speech_prompt else 0
@@ -56,7 +58,9 @@ class CFM(BaseModule):
             if noise.shape != (n_noise, B, F_, S):
                 raise ValueError(f"noise must have shape {(n_noise, B, F_, S)}, got {tuple(noise.shape)}")
         cfg = gradient_scale > 0
-        gp, io = self.estimator.get_plan(B, S, 2 if cfg else 1, bool(speech_prompt), dev)
+        gp, io = self.estimator.get_plan(B, S, 2 if cfg else 1, bool(speech_prompt), dev, ragged)
+        vl = (cond_lengths + 1).to(torch.int32)
+        io["kv_len"].copy_(torch.cat([vl, vl]) if cfg else vl)
         io["ids"].copy_(x)
         io["cond"].copy_(cond)
         condf = io["cond"]
