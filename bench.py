@@ -292,6 +292,25 @@ def main():
         "stage_ms": {k: round(v, 2) for k, v in stages.items()},
         "model_build_s": round(pipe.build_s, 1),
     }
+    # secondary rooflines (informational): MFMA-bound stages, algorithmic FLOPs from SURVEY.md §8d
+    mel = torch.randn(1, 80, pipe.frames, device=dev) * 2.1575 - 5.5419
+    pipe.voc(mel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    pipe.voc(mel)
+    e1.record()
+    torch.cuda.synchronize()
+    voc_ms = e0.elapsed_time(e1)
+    vb_ms = max(stages["voicebox_vocoder"] - voc_ms, 1e-3)
+    nfe = 2 * ((args.nt + 1) // 2) - 1
+    res["stage_rooflines"] = {
+        "voicebox": {"bound": "mfma", "dtype": "bf16", "tflop": round(1.734 * nfe, 1), "ms": round(vb_ms, 1),
+                     "achieved_tflops": round(1.734 * nfe / (vb_ms * 1e-3), 1), "peak_tflops": 2500.0},
+        "bigvgan": {"bound": "mfma", "dtype": "f32", "tflop": round(1.833e-3 * pipe.frames, 3), "ms": round(voc_ms, 2),
+                    "achieved_tflops": round(1.833e-3 * pipe.frames / (voc_ms * 1e-3), 1), "peak_tflops": 157.3},
+        "tokenizer": {"bound": "mfma", "dtype": "f32", "tflop": 0.80, "ms": round(stages["tokenizer"], 2),
+                      "achieved_tflops": round(0.80 / (stages["tokenizer"] * 1e-3), 1), "peak_tflops": 157.3},
+    }
     if rank == 0:
         res["roofline"] = measure_gemv_roofline(pipe.llm)
         if world == 1 and not args.no_cpu_baseline:
