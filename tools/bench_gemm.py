@@ -3,6 +3,7 @@ import sys
 import torch
 sys.path.insert(0, ".")
 from usdm_amd import ops
+from usdm_amd.graph import GraphedPlan
 
 dev = torch.device("cuda:0")
 
@@ -14,13 +15,17 @@ def bench(M, N, K, dtype=torch.bfloat16, act=0, residual=False, out16=True, reps
     R = torch.randn(M, N, device=dev) if residual else None
     o16 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16) if out16 else None
     o32 = None if out16 else torch.zeros(M, N, device=dev)
-    f = lambda: ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, act=act, residual=R, ldr=N, out16=o16, out32=o32, **kw)
+    # `reps` launches recorded once and replayed as one hipGraph: eager ops.gemm costs ~15 us of Python per call,
+    # which would hide any kernel shorter than that
+    plan = ops.Plan()
+    for _ in range(reps):
+        ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, act=act, residual=R, ldr=N, out16=o16, out32=o32, plan=plan, **kw)
+    gp = GraphedPlan(plan)
     for _ in range(3):
-        f()
+        gp.run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        f()
+    gp.run()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps

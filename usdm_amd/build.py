@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libusdm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
+FLAGS += os.environ.get("USDM_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DUSDM_GEMM_TRACE for tools/gemm_trace.py
 
 
 def _sources():

@@ -74,6 +74,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erfc(|z|) from Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, i.e.
+// ~1 ulp of the f32 result around |x| ~ 1): 1 + erf(z) = erfc(|z|) for z < 0 (no cancellation), 2 - erfc(|z|) otherwise.
+// ~15 VALU ops instead of the ~50 of the library erff: the GELU epilogue of the feed-forward GEMMs was VALU-bound.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t = __frcp_rn(__fmaf_rn(0.3275911f, az, 1.0f));
+  float p = __fmaf_rn(t, 1.061405429f, -1.453152027f);
+  p = __fmaf_rn(t, p, 1.421413741f);
+  p = __fmaf_rn(t, p, -0.284496736f);
+  p = __fmaf_rn(t, p, 0.254829592f);
+  const float q = p * t * __expf(-az * az);
+  return 0.5f * x * (z < 0.f ? q : 2.0f - q);
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -48,7 +48,16 @@ __device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
   return (g / (1.0f + __expf(-g))) * u;
 }
 
-template <typename T, int BM, int BN, int NWM, int NWN, bool DMA>   // NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct
+#ifdef USDM_GEMM_TRACE
+// debugging aid (tools/gemm_trace.py): per-workgroup phase timestamps (100 MHz wall clock) + hardware ids
+__device__ unsigned long long g_gemm_trace[8192 * 8];
+#define TR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
+
+template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2>
+// NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct with NST LDS stages of NCH 64-byte chunks each
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const usdm_gemm_args& a = g.a;
   constexpr int NTH = NWM * NWN * 64;
@@ -59,13 +68,18 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int TM = WTM / 16, TN = WTN / 16;  // 16x16 MFMA tiles per wave
   constexpr int LA = BM * 8 / NTH, LB = BN * 8 / NTH;  // 16-B loads per thread per K-step
   constexpr int RSTEP = NTH / 8;      // rows covered by one load pass
-  constexpr int STAGE = (BM + BN) * 128;     // bytes per LDS stage
+  constexpr int STAGE = (BM + BN) * 64 * NCH; // bytes per LDS stage
   constexpr int CST = BN + 4;                // f32 row stride of the epilogue tile (bank-conflict-free)
   constexpr int EPI = BM * CST * 4;
-  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  constexpr int SMEM = (NST * STAGE > EPI) ? NST * STAGE : EPI;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
+  TR(0);
+#ifdef USDM_GEMM_TRACE
+  if (tid == 0 && blockIdx.x < 8192)
+    g_gemm_trace[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+#endif
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 15, lc = lane >> 4;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
 
   const int cpt = a.Kc / CE;            // chunks per tap
   const int Q = a.taps * cpt;           // total chunks
-  const int nks = (Q + 1) >> 1;
+  const int nks = (Q + NCH - 1) / NCH;       // K-steps (NCH chunks each)
 
   // loader coordinates of this thread
   const int sub = (tid >> 2) & 1, pc = tid & 3, r0 = tid >> 3;
@@ -137,6 +151,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     }
   };
 
+  // epilogue ownership: thread -> 4 fixed output columns; their bias is fetched here, under the K loop
+  const int gcol = a.c_gcol * gz;
+  const float* bias = a.bias;
+  const bool swiglu = a.act == USDM_ACT_SWIGLU;
+  constexpr int C4 = BN / 4, RPI = NTH / C4, NIT = BM / RPI;
+  const int ec = (tid % C4) * 4, er = tid / C4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};   // SwiGLU: gate / up
+  if (bias) {
+    if (swiglu) {
+      const int c4 = (tid % (BN / 8)) * 4;
+      const int ngate = n0 + (c4 >> 4) * 32 + (c4 & 15);
+      if (ngate < a.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = bias[gcol + ngate + e]; bu[e] = bias[gcol + ngate + 16 + e]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + ec + e < a.N) bv[e] = bias[gcol + n0 + ec + e];
+    }
+  }
+
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
 
@@ -145,7 +181,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // receives logical piece c' ^ swz(r)), out-of-range rows/chunks are redirected past the descriptor (zeros).
   // Per-lane offsets of the wave-instructions this wave issues are loop invariants: only the chunk column
   // (+64 B per chunk) and, for multi-tap operands, the row shift change from K-step to K-step.
-  constexpr int QA = BM / 16 * 2, QB = BN / 16 * 2;      // wave-instructions per operand per K-step
+  constexpr int QA = BM / 16 * NCH, QB = BN / 16 * NCH;  // wave-instructions per operand per K-step
   constexpr int NWV = NWM * NWN;
   constexpr int NIA = (QA + NWV - 1) / NWV, NIB = (QB + NWV - 1) / NWV;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -176,15 +212,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // issue the wave-instructions [i0, i1) of operand A and [j0, j1) of operand W for K-step ks into `stage`
   auto dma_issue = [&](int stage, int ks, int i0, int i1, int j0, int j1) {
     char* sAst = smem + stage * STAGE;
-    char* sBst = sAst + BM * 128;
-    const unsigned kcol = (unsigned)(2 * ks * 64);       // 2 chunks of 64 B per K-step
+    char* sBst = sAst + BM * 64 * NCH;
+    const unsigned kcol = (unsigned)(NCH * ks * 64);     // NCH chunks of 64 B per K-step
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       if (i < i0 || i >= i1) continue;
       const int qi = wv + NWV * i;
       if (QA % NWV != 0 && qi >= QA) break;
       const int sb = qi / (BM / 16);
-      const int q = 2 * ks + sb;
+      const int q = NCH * ks + sb;
       unsigned off;
       if (simple) {
         off = (q < Q) ? dofA[i] + kcol : OOB;
@@ -204,16 +240,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       const int qi = wv + NWV * i;
       if (QB % NWV != 0 && qi >= QB) break;
       const int sb = qi / (BN / 16);
-      const unsigned off = (2 * ks + sb < Q) ? dofB[i] + kcol : OOB;
+      const unsigned off = (NCH * ks + sb < Q) ? dofB[i] + kcol : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBst + qi * 1024), 16, off, 0, 0, 0);
     }
   };
 
   auto compute = [&](int stage, auto&& between) {
     const char* sA = smem + stage * STAGE;
-    const char* sB = sA + BM * 128;
+    const char* sB = sA + BM * 64 * NCH;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NCH; ++s) {
       u32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -240,7 +276,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           }
         });
       });
-      if (s == 0) between();
+      if (s == 0 && NCH > 1) between();
     }
   };
 
@@ -250,24 +286,43 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr bool PF2 = (BM * BN <= 128 * 64) || (NTH > 256);
   if constexpr (DMA) {
     // two LDS stages; step ks+1 streams into the idle stage by LDS-DMA while step ks is multiplied
-    dma_issue(0, 0, 0, NIA, 0, NIB);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NST LDS stages: the DMA of K-step ks+NST-1 is issued while step ks is multiplied; a counted vmcnt leaves the
+    // youngest NST-2 steps in flight across the barrier (raw s_barrier: __syncthreads() would drain them).
+    constexpr int NPS = NIA + NIB;                         // DMA instructions per wave per K-step
+    constexpr int WCNT = (NST - 2) * NPS;                  // allowed outstanding after the per-step wait
+    static_assert(QA % NWV == 0 && QB % NWV == 0, "every wave must issue the same number of DMA instructions");
+    static_assert(WCNT <= 63, "vmcnt immediate");
+    TR(1);
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < nks) dma_issue(p, p, 0, NIA, 0, NIB);
+    if (nks >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TR(2);
+    int st = 0;
     for (int ks = 0; ks < nks; ++ks) {
-      // the next step's DMA is issued in two halves, one before each sub-chunk's MFMA cluster
-      const bool more = ks + 1 < nks;
-      if (more) dma_issue((ks + 1) & 1, ks + 1, 0, (NIA + 1) / 2, 0, (NIB + 1) / 2);
-      compute(ks & 1, [&]() { if (more) dma_issue((ks + 1) & 1, ks + 1, (NIA + 1) / 2, NIA, (NIB + 1) / 2, NIB); });
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      const bool more = ks + NST - 1 < nks;
+      int stn = st + NST - 1; if (stn >= NST) stn -= NST;
+      if (more) dma_issue(stn, ks + NST - 1, 0, (NIA + 1) / 2, 0, (NIB + 1) / 2);
+      compute(st, [&]() { if (more) dma_issue(stn, ks + NST - 1, (NIA + 1) / 2, NIA, (NIB + 1) / 2, NIB); });
+      if (NCH == 1 && more) dma_issue(stn, ks + NST - 1, (NIA + 1) / 2, NIA, (NIB + 1) / 2, NIB);
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCNT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (++st == NST) st = 0;
     }
+    __syncthreads();
   } else {
+  TR(1);
   load_regs(0, ra0, rb0);
   store_lds(0, ra0, rb0);
   if (nks > 1) load_regs(1, ra0, rb0);
   if constexpr (PF2) {
     if (nks > 2) load_regs(2, ra1, rb1);
     __syncthreads();
+    TR(2);
     for (int ks = 0; ks < nks; ks += 2) {
       compute(0, []() {});
       if (ks + 1 < nks) store_lds(1, ra0, rb0);
@@ -291,6 +346,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   }
 
   // ------------------------------------------------------------------ epilogue through LDS
+  // Every thread owns FIXED output columns (4 consecutive n in the row-major pass), so its bias values were fetched
+  // before the K loop (bv/bu above) and residual rows are fetched a batch at a time ahead of their use: a load
+  // inside the store loop costs a full memory latency per iteration (measured: 14 us of a 33 us 128x128 tile).
+  TR(3);
   float* ct = (float*)smem;  // [BM][CST] f32
   static_for<TM>([&](auto I) {
     static_for<TN>([&](auto J) {
@@ -301,160 +360,230 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     });
   });
   __syncthreads();
+  TR(4);
 
-  const int gcol = a.c_gcol * gz;
-  const float* bias = a.bias;
   const bool rbf = a.round_bf16 != 0;
   const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
+  const bool col_major_out = a.transpose_out != 0;
 
-  if (a.act == USDM_ACT_SWIGLU) {
+  if (swiglu) {
     // column tiles (2p, 2p+1) of 16 hold gate / up of the same 16 output features
-    constexpr int OC = BN / 2;  // output columns of this tile
-    for (int idx = tid; idx < BM * (OC / 4); idx += NTH) {
-      const int r = idx / (OC / 4), c4 = (idx - r * (OC / 4)) * 4;
-      const int m = m0 + r;
-      const int cg = (c4 >> 4) * 32 + (c4 & 15);   // gate column inside the tile
-      const int ngate = n0 + cg;
-      if (m >= a.M || ngate >= a.N) continue;
-      const float4 gv = *(const float4*)(ct + r * CST + cg), uv = *(const float4*)(ct + r * CST + cg + 16);
-      float gt[4] = {gv.x, gv.y, gv.z, gv.w}, up[4] = {uv.x, uv.y, uv.z, uv.w}, o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float gg = a.alpha * gt[e], uu = a.alpha * up[e];
-        if (bias) { gg += bias[gcol + ngate + e]; uu += bias[gcol + ngate + 16 + e]; }
-        o[e] = silu_mul(gg, uu, rbf);
-      }
+    constexpr int OC4 = BN / 8, RPS = NTH / OC4, NIS = BM / RPS;
+    const int c4 = (tid % OC4) * 4, rr = tid / OC4;
+    const int cg = (c4 >> 4) * 32 + (c4 & 15);   // gate column inside the tile
+    const int ngate = n0 + cg;
+    if (ngate < a.N) {
       const int nout = (n0 >> 1) + c4;
-      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-      const int64_t oi = row * a.ldc + (gcol >> 1) + nout;
-      if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
-      if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+#pragma unroll 2
+      for (int it = 0; it < NIS; ++it) {
+        const int r = rr + it * RPS, m = m0 + r;
+        if (m >= a.M) break;
+        const float4 gv = *(const float4*)(ct + r * CST + cg), uv = *(const float4*)(ct + r * CST + cg + 16);
+        const float gt[4] = {gv.x, gv.y, gv.z, gv.w}, up[4] = {uv.x, uv.y, uv.z, uv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = silu_mul(a.alpha * gt[e] + bv[e], a.alpha * up[e] + bu[e], rbf);
+        const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+        const int64_t oi = row * a.ldc + (gcol >> 1) + nout;
+        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+      }
     }
     return;
   }
 
-  // value after bias / activation (before residual)
-  auto pre = [&](float x, int n) -> float {
-    x = a.alpha * x + (bias ? bias[gcol + n] : 0.f);
-    if (rbf) x = round_bf(x);
-    if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
-    else if (a.act == USDM_ACT_TANH) x = tanhf(x);
-    else if (a.act == USDM_ACT_LOGCLAMP) x = logf(fmaxf(x, 1e-5f));
-    return x;
-  };
+  // ---- pass A (only when an activation or a transposed store follows): alpha, bias, bf16 rounding and the activation
+  // are applied in place to this thread's own 4 columns, in a ROLLED loop so the transcendental code exists once
+  // (an unrolled epilogue grew the kernel to 88 KB and ran out of the instruction cache).
+  const bool applied = a.act != USDM_ACT_NONE || col_major_out || is_qkv;
+  if (applied) {
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+      float4* cp = (float4*)(ct + (er + it * RPI) * CST + ec);
+      const float4 cv = *cp;
+      float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = a.alpha * v[e] + bv[e];
+        if (rbf) x = round_bf(x);
+        if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
+        else if (a.act == USDM_ACT_TANH) x = tanhf(x);
+        else if (a.act == USDM_ACT_LOGCLAMP) x = logf(fmaxf(x, 1e-5f));
+        v[e] = x;
+      }
+      *cp = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (col_major_out || is_qkv) __syncthreads();   // pass 2 reads other threads' columns
+  }
 
-  const bool col_major_out = a.transpose_out != 0;
   // ---- pass 1: outputs whose fast axis is n (row-major C, Q and K of the head-split epilogue)
   if (!col_major_out) {
+    const int n = n0 + ec;
+    const int nv = (a.N - n) < 4 ? (a.N - n) : 4;   // <= 0: this thread's columns are outside the matrix
     const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
-    for (int idx = tid; idx < BM * (BN / 4); idx += NTH) {
-      const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
-      const int m = m0 + r, n = n0 + c4;
-      if (m >= a.M || n >= a.N) continue;
-      const float4 cv = *(const float4*)(ct + r * CST + c4);
-      float v[4] = {cv.x, cv.y, cv.z, cv.w};
-      const int nv = (a.N - n) < 4 ? (a.N - n) : 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = e < nv ? pre(v[e], n + e) : 0.f;
-      if (is_qkv) {
-        const int HD = a.qkv_H * a.qkv_D;
-        const int part = n / HD;
-        if (part == 2) continue;  // V is stored transposed in pass 2
-        const int hn = n - part * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-        const int b = m / a.qkv_S, s = m - b * a.qkv_S;
-        bf16_t* dst = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k) + (((int64_t)b * a.qkv_H + h) * a.qkv_Spad + s) * a.qkv_D + d;
-        uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
-        *(uint2*)dst = p;   // D % 4 == 0 and N % 4 == 0 are checked on the host
-        continue;
-      }
-      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-      if (a.residual) {
-        const int64_t ri = row * a.ldr + gcol + n;
-        if (vec_ok && nv == 4) {
-          if (a.res_dtype == USDM_F32) {
-            const float4 rv = *(const float4*)((const float*)a.residual + ri);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          } else {
-            const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
-            v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
-          }
-        } else {
-          for (int e = 0; e < nv; ++e)
-            v[e] += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri + e] : bf2f(((const bf16_t*)a.residual)[ri + e]);
-        }
-        if (rbf) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
-        }
-      }
-      const int64_t oi = row * a.ldc + gcol + n;
-      if (vec_ok && nv == 4) {
-        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
-      } else {
-        for (int e = 0; e < nv; ++e) {
-          if (a.C32) ((float*)a.C32)[oi + e] = v[e];
-          if (a.C16) ((bf16_t*)a.C16)[oi + e] = f2bf(v[e]);
-        }
-      }
-    }
-    if (!is_qkv) return;
-  }
-  // ---- pass 2: outputs whose fast axis is m (transpose_out, V^T of the head-split epilogue)
-  for (int idx = tid; idx < BN * (BM / 4); idx += NTH) {
-    const int c = idx / (BM / 4), r4 = (idx - c * (BM / 4)) * 4;
-    const int n = n0 + c, m = m0 + r4;
-    if (n >= a.N || m >= a.M) continue;
-    const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = e < mv ? pre(ct[(r4 + e) * CST + c], n) : 0.f;
+    const float al = applied ? 1.f : a.alpha;
+    const bool rb1 = rbf && !applied;
     if (is_qkv) {
       const int HD = a.qkv_H * a.qkv_D;
-      if (n < 2 * HD) continue;
-      const int hn = n - 2 * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-      const int b0 = m / a.qkv_S, s0 = m - b0 * a.qkv_S;
-      bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
-      if (mv == 4 && s0 + 3 < a.qkv_S && (s0 & 1) == 0) {        // 4 tokens of one sequence: two packed 4-byte stores
-        *(unsigned*)(vrow + s0) = pack_bf2(v[0], v[1]);
-        *(unsigned*)(vrow + s0 + 2) = pack_bf2(v[2], v[3]);
-      } else {
-        for (int e = 0; e < mv; ++e) {
-          const int mm = m + e, b = mm / a.qkv_S, s = mm - b * a.qkv_S;
-          ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s] = f2bf(v[e]);
+      const int part = nv > 0 ? n / HD : 2;
+      if (part < 2) {                                // V is stored transposed in pass 2
+        const int hn = n - part * HD, qh = hn / a.qkv_D, qd = hn - qh * a.qkv_D;
+        bf16_t* base = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k);
+#pragma unroll 2
+        for (int it = 0; it < NIT; ++it) {
+          const int r = er + it * RPI, m = m0 + r;
+          if (m >= a.M) break;
+          const float4 cv = *(const float4*)(ct + r * CST + ec);
+          const int b = m / a.qkv_S, sq = m - b * a.qkv_S;
+          uint2 p; p.x = pack_bf2(cv.x, cv.y); p.y = pack_bf2(cv.z, cv.w);
+          *(uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;   // D % 4 == 0, N % 4 == 0 (host-checked)
         }
       }
-      continue;
-    }
-    const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-    for (int e = 0; e < mv; ++e) {
-      const int64_t rw = row + (int64_t)e * a.c_row_mul;
-      float x = v[e];
-      if (a.residual) {
-        const int64_t ri = rw * a.ldr + gcol + n;
-        x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
-        if (rbf) x = round_bf(x);
+    } else if (nv == 4 && vec_ok) {
+      constexpr int NB = NIT < 8 ? NIT : 8;
+      static_assert(NIT % NB == 0, "epilogue batches");
+      const bool has_res = a.residual != nullptr;
+      const int64_t rstep = (int64_t)RPI * a.c_row_mul;
+      int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += NB) {
+        float4 rres[NB];
+        if (has_res) {                                // the whole batch of residual rows is in flight before its first use
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const int m = m0 + er + (it0 + u) * RPI;
+            rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M) {
+              const int64_t ri = (row + u * rstep) * a.ldr + gcol + n;
+              if (a.res_dtype == USDM_F32) {
+                rres[u] = *(const float4*)((const float*)a.residual + ri);
+              } else {
+                const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+                rres[u] = make_float4(bf2f(rv.x & 0xffff), bf2f(rv.x >> 16), bf2f(rv.y & 0xffff), bf2f(rv.y >> 16));
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int r = er + (it0 + u) * RPI, m = m0 + r;
+          if (m >= a.M) break;
+          const float4 cv = *(const float4*)(ct + r * CST + ec);
+          float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = al * v[e] + (applied ? 0.f : bv[e]);
+            if (rb1) v[e] = round_bf(v[e]);
+          }
+          if (has_res) {
+            v[0] += rres[u].x; v[1] += rres[u].y; v[2] += rres[u].z; v[3] += rres[u].w;
+            if (rbf) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
+            }
+          }
+          const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
+          if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+          if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+        }
+        row += NB * rstep;
       }
-      const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
-      if (a.C32) ((float*)a.C32)[oi] = x;
-      if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+    } else if (nv > 0) {
+      // ragged / unaligned columns (N or ldc not a multiple of 4): scalar accesses, rolled
+#pragma unroll 1
+      for (int it = 0; it < NIT; ++it) {
+        const int r = er + it * RPI, m = m0 + r;
+        if (m >= a.M) break;
+        const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+        for (int e = 0; e < nv; ++e) {
+          float x = al * ct[r * CST + ec + e] + (applied ? 0.f : bv[e]);
+          if (rb1) x = round_bf(x);
+          if (a.residual) {
+            const int64_t ri = row * a.ldr + gcol + n + e;
+            x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+            if (rbf) x = round_bf(x);
+          }
+          const int64_t oi = row * a.ldc + gcol + n + e;
+          if (a.C32) ((float*)a.C32)[oi] = x;
+          if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+        }
+      }
+    }
+#ifdef USDM_GEMM_TRACE
+    TR(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR(5);
+#endif
+    if (!is_qkv) return;
+    if (n0 + BN <= 2 * a.qkv_H * a.qkv_D) return;   // no V columns in this tile
+  }
+  // ---- pass 2: outputs whose fast axis is m (transpose_out, V^T of the head-split epilogue); values are final in ct
+  {
+    constexpr int R4 = BM / 4, CPI = NTH / R4, NIT2 = BN / CPI;
+    const int r4 = (tid % R4) * 4, c0 = tid / R4;
+    const int m = m0 + r4;
+    const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
+    if (mv <= 0) return;
+    const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+    const int b0 = is_qkv ? m / a.qkv_S : 0, s0 = is_qkv ? m - b0 * a.qkv_S : 0;
+#pragma unroll 2
+    for (int it = 0; it < NIT2; ++it) {
+      const int c = c0 + it * CPI, n = n0 + c;
+      if (n >= a.N) break;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = e < mv ? ct[(r4 + e) * CST + c] : 0.f;
+      if (is_qkv) {
+        const int HD = a.qkv_H * a.qkv_D;
+        if (n < 2 * HD) continue;
+        const int hn = n - 2 * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
+        bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
+        if (mv == 4 && s0 + 3 < a.qkv_S && (s0 & 1) == 0) {        // 4 tokens of one sequence: two packed 4-byte stores
+          *(unsigned*)(vrow + s0) = pack_bf2(v[0], v[1]);
+          *(unsigned*)(vrow + s0 + 2) = pack_bf2(v[2], v[3]);
+        } else {
+          for (int e = 0; e < mv; ++e) {
+            const int mm = m + e, b = mm / a.qkv_S, sq = mm - b * a.qkv_S;
+            ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + sq] = f2bf(v[e]);
+          }
+        }
+        continue;
+      }
+      for (int e = 0; e < mv; ++e) {
+        const int64_t rw = row + (int64_t)e * a.c_row_mul;
+        float x = v[e];
+        if (a.residual) {
+          const int64_t ri = rw * a.ldr + gcol + n;
+          x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+          if (rbf) x = round_bf(x);
+        }
+        const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
+        if (a.C32) ((float*)a.C32)[oi] = x;
+        if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+      }
     }
   }
 }
 
-template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false>
+template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
   GemmDev g;
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA>), grid, dim3(NWM * NWN * 64), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
+
+#ifdef USDM_GEMM_TRACE
+extern "C" int usdm_dbg_gemm_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(pa != nullptr, "usdm_gemm: null args");
@@ -501,7 +630,16 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   // In-situ measurements (tools/stage_times.py, profiles/r01_gemm_ablation.txt): with operands coming from HBM/MALL
   // rather than a hot L2, the register-staged loaders (two K-steps in flight) beat the single-stage LDS-DMA loaders on
   // the mid-size shapes of the path; the DMA variant is used where it wins clearly: large single-tap GEMMs.
+  // USDM_GEMM_HEUR=1: the microbenchmark-optimal choice (hot L2) that prefers the LDS-DMA variants; in situ it is
+  // ~2 % slower for the Voicebox layer (weights stream from HBM), so it stays an experiment switch.
+  static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 0;
   if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
+  else if (heur == 1 && a.taps == 1) {
+    if (t128 >= 400) sel = 4;
+    else if (t128 >= 150 && a.Kc >= 2048) sel = 11;
+    else if (t12864 >= 256 && a.Kc >= 2048) sel = 10;
+    else sel = 5;
+  }
   else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
@@ -511,6 +649,11 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);
     if (sel == 5) return launch<bf16_t, 64, 64, 2, 2, true>(a, st);
     if (sel == 6) return launch<bf16_t, 128, 64, 2, 2, true>(a, st);
+    if (sel == 7) return launch<bf16_t, 64, 64, 2, 2, true, 3, 2>(a, st);
+    if (sel == 8) return launch<bf16_t, 64, 64, 2, 2, true, 4, 2>(a, st);
+    if (sel == 9) return launch<bf16_t, 128, 128, 2, 2, true, 4, 1>(a, st);
+    if (sel == 10) return launch<bf16_t, 128, 64, 2, 2, true, 3, 2>(a, st);
+    if (sel == 11) return launch<bf16_t, 128, 128, 2, 2, true, 3, 2>(a, st);
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
@@ -519,6 +662,11 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 4) return launch<float, 128, 128, 2, 2, true>(a, st);
     if (sel == 5) return launch<float, 64, 64, 2, 2, true>(a, st);
     if (sel == 6) return launch<float, 128, 64, 2, 2, true>(a, st);
+    if (sel == 7) return launch<float, 64, 64, 2, 2, true, 3, 2>(a, st);
+    if (sel == 8) return launch<float, 64, 64, 2, 2, true, 4, 2>(a, st);
+    if (sel == 9) return launch<float, 128, 128, 2, 2, true, 4, 1>(a, st);
+    if (sel == 10) return launch<float, 128, 64, 2, 2, true, 3, 2>(a, st);
+    if (sel == 11) return launch<float, 128, 128, 2, 2, true, 3, 2>(a, st);
     if (sel == 0) return launch<float, 128, 128>(a, st);
     if (sel == 1) return launch<float, 128, 64>(a, st);
     return launch<float, 64, 64>(a, st);
