@@ -261,6 +261,8 @@ typedef struct usdm_attn_decode_args {
   void* kcache; void* vcache;
   float* pm; float* pl; float* po; /* scratch [Hq][NS], [Hq][NS], [Hq][NS][128] */
   void* out;
+  int32_t* counters; /* [Hkv] zero-initialised once, self-resetting: when given (NS > 1) the workgroup that finishes a
+                        kv head last merges its NS partials itself and no separate combine kernel is launched */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

@@ -11,13 +11,21 @@ sys.path.insert(0, ".")
 from usdm_amd import ops, _lib
 
 M, N, K = (int(x) for x in sys.argv[1:4])
+QKV = "--qkv" in sys.argv   # head-split epilogue of the Voicebox layer (N = 3 * 16 * 64)
 dev = torch.device("cuda:0")
 A = torch.randn(M, K, device=dev).bfloat16()
 W = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
 bias = torch.randn(N, device=dev)
 out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+if QKV:
+    S = M // 2; Spad = (S + 63) // 64 * 64
+    q = torch.zeros(2, 16, Spad, 64, device=dev, dtype=torch.bfloat16); k = torch.zeros_like(q)
+    vt = torch.zeros(2, 16, 64, Spad, device=dev, dtype=torch.bfloat16)
 for _ in range(5):
-    ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, out16=out)
+    if QKV:
+        ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, qkv=dict(S=S, Spad=Spad, H=16, D=64, q=q, k=k, v=vt))
+    else:
+        ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, out16=out)
 torch.cuda.synchronize()
 lib = _lib.lib
 buf = np.zeros(8192 * 8, dtype=np.uint64)
@@ -42,6 +50,16 @@ for i, nm in enumerate(names):
     print(f"  {nm:18s} median {np.median(d):6.2f} us  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}")
 d = ns(t[:, 6] - t[:, 4]) / 1e3
 print(f"  {'  stores issued':18s} median {np.median(d):6.2f} us  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}")
+if QKV:   # the last third of the tiles along N holds V (transposed store)
+    bm = 128 if nwg in (18 * 24, 18 * 48) else 64
+    tiles_n = nwg // ((M + bm - 1) // bm)
+    q8, r8 = nwg // 8, nwg % 8
+    bid = np.arange(nwg); xcd = bid & 7; idx = bid >> 3
+    tile = np.where(xcd < r8, xcd * (q8 + 1), r8 * (q8 + 1) + (xcd - r8) * q8) + idx
+    isv = (tile % tiles_n) >= (2 * tiles_n) // 3
+    for nm, sel in (("Q/K tiles", ~isv), ("V tiles", isv)):
+        dd = ns(t[sel, 5] - t[sel, 4]) / 1e3
+        print(f"  epilogue, {nm:10s} median {np.median(dd):6.2f} us  p10 {np.percentile(dd, 10):6.2f}  p90 {np.percentile(dd, 90):6.2f}  (n={sel.sum()})")
 d = ns(t[:, 5] - t[:, 0]) / 1e3
 print(f"  {'whole workgroup':18s} median {np.median(d):6.2f} us  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}")
 # concurrency: workgroups resident per CU at the midpoint of the first workgroup on it

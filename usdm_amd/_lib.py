@@ -132,7 +132,7 @@ class AttnDecodeArgs(C.Structure):
         ("Hq", C.c_int32), ("Hkv", C.c_int32), ("ctx_max", C.c_int32), ("NS", C.c_int32), ("scale", C.c_float),
         ("cos", C.c_void_p), ("sin", C.c_void_p),
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
-        ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p),
+        ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
     ]
 
 

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int RSTEP = NTH / 8;      // rows covered by one load pass
   constexpr int STAGE = (BM + BN) * 64 * NCH; // bytes per LDS stage
   constexpr int CST = BN + 4;                // f32 row stride of the epilogue tile (bank-conflict-free)
-  constexpr int EPI = BM * CST * 4;
+  constexpr int CSTT = BM + 16;              // f32 column stride of the TRANSPOSED epilogue tile (outputs whose fast axis is m)
+  constexpr int EPI = (BM * CST > BN * CSTT ? BM * CST : BN * CSTT) * 4;
   constexpr int SMEM = (NST * STAGE > EPI) ? NST * STAGE : EPI;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -172,6 +173,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         if (n0 + ec + e < a.N) bv[e] = bias[gcol + n0 + ec + e];
     }
   }
+
+  // outputs whose fast axis is m (transpose_out, V^T tiles of the head-split epilogue) go through a transposed LDS tile;
+  // their per-column bias is staged in LDS here (visible after the K loop's barriers)
+  const bool tr_mode = a.transpose_out != 0 || (a.epi == USDM_EPI_QKV_HEADS && n0 >= 2 * a.qkv_H * a.qkv_D);
+  __shared__ float sb[BN];
+  if (tr_mode)
+    for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;
 
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
@@ -350,7 +358,107 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // before the K loop (bv/bu above) and residual rows are fetched a batch at a time ahead of their use: a load
   // inside the store loop costs a full memory latency per iteration (measured: 14 us of a 33 us 128x128 tile).
   TR(3);
-  float* ct = (float*)smem;  // [BM][CST] f32
+  float* ct = (float*)smem;  // [BM][CST] f32, or [BN][CSTT] in transposed mode
+  const bool rbf = a.round_bf16 != 0;
+  const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
+
+  if (tr_mode) {
+    // ---- transposed mode: the accumulator fragment of a lane is 4 consecutive rows of one column, i.e. one float4 of the
+    // transposed tile; the store loop then reads float4s along m without bank conflicts (a strided read of the row-major
+    // tile was 8-way conflicted: 10 us per 128x128 V tile)
+    static_for<TM>([&](auto I) {
+      static_for<TN>([&](auto J) {
+        const int col = wn * WTN + J * 16 + lr;
+        const int row = wm * WTM + I * 16 + lc * 4;
+        *(float4*)(ct + col * CSTT + row) = make_float4(acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]);
+      });
+    });
+    __syncthreads();
+    TR(4);
+    if (is_qkv) {
+      // V^T[b][h][d][s]: lane = 2 consecutive tokens, a wave (or half-wave) = one feature -> dense 4-byte-per-lane stores
+      constexpr int R2 = BM / 2, CPI2 = NTH / R2, NITV = BN / CPI2;
+      const int r2 = (tid % R2) * 2, c0v = tid / R2;
+      const int m = m0 + r2;
+      if (m < a.M) {
+        const int HD2 = 2 * a.qkv_H * a.qkv_D;
+        const int b0 = m / a.qkv_S, s0 = m - b0 * a.qkv_S;
+        const bool pair = (m + 1 < a.M) && (s0 + 1 < a.qkv_S) && ((s0 & 1) == 0);
+        float2 cv = *(const float2*)(ct + c0v * CSTT + r2);
+#pragma unroll 4
+        for (int it = 0; it < NITV; ++it) {
+          const int c = c0v + it * CPI2, n = n0 + c;
+          if (n >= a.N) break;
+          float v0 = cv.x, v1 = cv.y;
+          if (it + 1 < NITV) cv = *(const float2*)(ct + (c + CPI2) * CSTT + r2);
+          const float bc = sb[c];
+          v0 = a.alpha * v0 + bc; v1 = a.alpha * v1 + bc;
+          if (rbf) { v0 = round_bf(v0); v1 = round_bf(v1); }
+          const int hn = n - HD2, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
+          bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
+          if (pair) {
+            *(unsigned*)(vrow + s0) = pack_bf2(v0, v1);
+          } else {
+            vrow[s0] = f2bf(v0);
+            if (m + 1 < a.M) {                               // second token starts the next sequence
+              const int b1 = (m + 1) / a.qkv_S, s1 = (m + 1) - b1 * a.qkv_S;
+              ((bf16_t*)a.qkv_v)[(((int64_t)b1 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s1] = f2bf(v1);
+            }
+          }
+        }
+      }
+#ifdef USDM_GEMM_TRACE
+      TR(6);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TR(5);
+#endif
+      return;
+    }
+    constexpr int R4 = BM / 4, CPI = NTH / R4, NIT2 = BN / CPI;
+    const int r4 = (tid % R4) * 4, c0 = tid / R4;
+    const int m = m0 + r4;
+    const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
+    if (mv > 0) {
+      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+      float4 cv = *(const float4*)(ct + c0 * CSTT + r4);
+#pragma unroll 2
+      for (int it = 0; it < NIT2; ++it) {
+        const int c = c0 + it * CPI, n = n0 + c;
+        if (n >= a.N) break;
+        float v[4] = {cv.x, cv.y, cv.z, cv.w};
+        if (it + 1 < NIT2) cv = *(const float4*)(ct + (c + CPI) * CSTT + r4);
+        const float bc = sb[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = a.alpha * v[e] + bc;
+          if (rbf) x = round_bf(x);
+          if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
+          else if (a.act == USDM_ACT_TANH) x = tanhf(x);
+          else if (a.act == USDM_ACT_LOGCLAMP) x = logf(fmaxf(x, 1e-5f));
+          v[e] = x;
+        }
+        for (int e = 0; e < mv; ++e) {
+          const int64_t rw = row + (int64_t)e * a.c_row_mul;
+          float x = v[e];
+          if (a.residual) {
+            const int64_t ri = rw * a.ldr + gcol + n;
+            x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+            if (rbf) x = round_bf(x);
+          }
+          const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
+          if (a.C32) ((float*)a.C32)[oi] = x;
+          if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
+        }
+      }
+    }
+#ifdef USDM_GEMM_TRACE
+    TR(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR(5);
+#endif
+    return;
+  }
+
   static_for<TM>([&](auto I) {
     static_for<TN>([&](auto J) {
       const int col = wn * WTN + J * 16 + lr;
@@ -361,10 +469,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   });
   __syncthreads();
   TR(4);
-
-  const bool rbf = a.round_bf16 != 0;
-  const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
-  const bool col_major_out = a.transpose_out != 0;
 
   if (swiglu) {
     // column tiles (2p, 2p+1) of 16 hold gate / up of the same 16 output features
@@ -392,177 +496,154 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     return;
   }
 
-  // ---- pass A (only when an activation or a transposed store follows): alpha, bias, bf16 rounding and the activation
-  // are applied in place to this thread's own 4 columns, in a ROLLED loop so the transcendental code exists once
-  // (an unrolled epilogue grew the kernel to 88 KB and ran out of the instruction cache).
-  const bool applied = a.act != USDM_ACT_NONE || col_major_out || is_qkv;
-  if (applied) {
-#pragma unroll 1
-    for (int it = 0; it < NIT; ++it) {
-      float4* cp = (float4*)(ct + (er + it * RPI) * CST + ec);
-      const float4 cv = *cp;
+  // ---- row-major outputs (and Q / K tiles of the head-split epilogue): thread = 4 fixed columns, rows er, er + RPI, ...
+  const int n = n0 + ec;
+  const int nv = (a.N - n) < 4 ? (a.N - n) : 4;   // <= 0: this thread's columns are outside the matrix
+  const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
+  auto act_fn = [&](float x) -> float {
+    if (a.act == USDM_ACT_GELU) return gelu_erf(x);
+    if (a.act == USDM_ACT_TANH) return tanhf(x);
+    if (a.act == USDM_ACT_LOGCLAMP) return logf(fmaxf(x, 1e-5f));
+    return x;
+  };
+  if (is_qkv) {
+    if (nv > 0) {
+      const int HD = a.qkv_H * a.qkv_D;
+      const int part = n / HD;                        // 0: Q, 1: K (V tiles took the transposed path)
+      const int hn = n - part * HD, qh = hn / a.qkv_D, qd = hn - qh * a.qkv_D;
+      bf16_t* base = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k);
+      float4 cv = *(const float4*)(ct + er * CST + ec);
+#pragma unroll 2
+      for (int it = 0; it < NIT; ++it) {
+        const int r = er + it * RPI, m = m0 + r;
+        if (m >= a.M) break;
+        float v[4] = {cv.x, cv.y, cv.z, cv.w};
+        if (it + 1 < NIT) cv = *(const float4*)(ct + (r + RPI) * CST + ec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = a.alpha * v[e] + bv[e];
+          if (rbf) v[e] = round_bf(v[e]);
+        }
+        const int b = m / a.qkv_S, sq = m - b * a.qkv_S;
+        uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;   // D % 4 == 0, N % 4 == 0 (host-checked)
+      }
+    }
+  } else if (nv == 4 && vec_ok && a.act != USDM_ACT_NONE) {
+    // activation epilogues: ROLLED loop so the transcendental code exists once (an unrolled epilogue grew the kernel to
+    // 88 KB and ran out of the instruction cache); the next row's LDS read is issued under this row's math
+    const bool has_res = a.residual != nullptr;
+    const int64_t rstep = (int64_t)RPI * a.c_row_mul;
+    int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
+    float4 cv = *(const float4*)(ct + er * CST + ec);
+#pragma unroll 2
+    for (int it = 0; it < NIT; ++it, row += rstep) {
+      const int r = er + it * RPI;
+      if (m0 + r >= a.M) break;
       float v[4] = {cv.x, cv.y, cv.z, cv.w};
+      if (it + 1 < NIT) cv = *(const float4*)(ct + (r + RPI) * CST + ec);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float x = a.alpha * v[e] + bv[e];
         if (rbf) x = round_bf(x);
-        if (a.act == USDM_ACT_GELU) x = gelu_erf(x);
-        else if (a.act == USDM_ACT_TANH) x = tanhf(x);
-        else if (a.act == USDM_ACT_LOGCLAMP) x = logf(fmaxf(x, 1e-5f));
-        v[e] = x;
+        v[e] = act_fn(x);
       }
-      *cp = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (col_major_out || is_qkv) __syncthreads();   // pass 2 reads other threads' columns
-  }
-
-  // ---- pass 1: outputs whose fast axis is n (row-major C, Q and K of the head-split epilogue)
-  if (!col_major_out) {
-    const int n = n0 + ec;
-    const int nv = (a.N - n) < 4 ? (a.N - n) : 4;   // <= 0: this thread's columns are outside the matrix
-    const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
-    const float al = applied ? 1.f : a.alpha;
-    const bool rb1 = rbf && !applied;
-    if (is_qkv) {
-      const int HD = a.qkv_H * a.qkv_D;
-      const int part = nv > 0 ? n / HD : 2;
-      if (part < 2) {                                // V is stored transposed in pass 2
-        const int hn = n - part * HD, qh = hn / a.qkv_D, qd = hn - qh * a.qkv_D;
-        bf16_t* base = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k);
-#pragma unroll 2
-        for (int it = 0; it < NIT; ++it) {
-          const int r = er + it * RPI, m = m0 + r;
-          if (m >= a.M) break;
-          const float4 cv = *(const float4*)(ct + r * CST + ec);
-          const int b = m / a.qkv_S, sq = m - b * a.qkv_S;
-          uint2 p; p.x = pack_bf2(cv.x, cv.y); p.y = pack_bf2(cv.z, cv.w);
-          *(uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;   // D % 4 == 0, N % 4 == 0 (host-checked)
+      if (has_res) {
+        const int64_t ri = row * a.ldr + gcol + n;
+        if (a.res_dtype == USDM_F32) {
+          const float4 rv = *(const float4*)((const float*)a.residual + ri);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        } else {
+          const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+          v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
         }
-      }
-    } else if (nv == 4 && vec_ok) {
-      constexpr int NB = NIT < 8 ? NIT : 8;
-      static_assert(NIT % NB == 0, "epilogue batches");
-      const bool has_res = a.residual != nullptr;
-      const int64_t rstep = (int64_t)RPI * a.c_row_mul;
-      int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
-#pragma unroll 1
-      for (int it0 = 0; it0 < NIT; it0 += NB) {
-        float4 rres[NB];
-        if (has_res) {                                // the whole batch of residual rows is in flight before its first use
+        if (rbf) {
 #pragma unroll
-          for (int u = 0; u < NB; ++u) {
-            const int m = m0 + er + (it0 + u) * RPI;
-            rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < a.M) {
-              const int64_t ri = (row + u * rstep) * a.ldr + gcol + n;
-              if (a.res_dtype == USDM_F32) {
-                rres[u] = *(const float4*)((const float*)a.residual + ri);
-              } else {
-                const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
-                rres[u] = make_float4(bf2f(rv.x & 0xffff), bf2f(rv.x >> 16), bf2f(rv.y & 0xffff), bf2f(rv.y >> 16));
-              }
-            }
-          }
+          for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
         }
+      }
+      const int64_t oi = row * a.ldc + gcol + n;
+      if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+    }
+  } else if (nv == 4 && vec_ok) {
+    // no activation: batches of NB rows, the residual rows of a batch all in flight before their first use (a load inside
+    // the store loop costs a full memory latency per iteration: measured 14 us of a 33 us 128x128 tile)
+    constexpr int NB = NIT < 8 ? NIT : 8;
+    static_assert(NIT % NB == 0, "epilogue batches");
+    const bool has_res = a.residual != nullptr;
+    const int64_t rstep = (int64_t)RPI * a.c_row_mul;
+    int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += NB) {
+      float4 rres[NB];
+      if (has_res) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const int r = er + (it0 + u) * RPI, m = m0 + r;
-          if (m >= a.M) break;
-          const float4 cv = *(const float4*)(ct + r * CST + ec);
-          float v[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = al * v[e] + (applied ? 0.f : bv[e]);
-            if (rb1) v[e] = round_bf(v[e]);
-          }
-          if (has_res) {
-            v[0] += rres[u].x; v[1] += rres[u].y; v[2] += rres[u].z; v[3] += rres[u].w;
-            if (rbf) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
+          const int m = m0 + er + (it0 + u) * RPI;
+          rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < a.M) {
+            const int64_t ri = (row + u * rstep) * a.ldr + gcol + n;
+            if (a.res_dtype == USDM_F32) {
+              rres[u] = *(const float4*)((const float*)a.residual + ri);
+            } else {
+              const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+              rres[u] = make_float4(bf2f(rv.x & 0xffff), bf2f(rv.x >> 16), bf2f(rv.y & 0xffff), bf2f(rv.y >> 16));
             }
           }
-          const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
-          if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
-          if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
-        }
-        row += NB * rstep;
-      }
-    } else if (nv > 0) {
-      // ragged / unaligned columns (N or ldc not a multiple of 4): scalar accesses, rolled
-#pragma unroll 1
-      for (int it = 0; it < NIT; ++it) {
-        const int r = er + it * RPI, m = m0 + r;
-        if (m >= a.M) break;
-        const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-        for (int e = 0; e < nv; ++e) {
-          float x = al * ct[r * CST + ec + e] + (applied ? 0.f : bv[e]);
-          if (rb1) x = round_bf(x);
-          if (a.residual) {
-            const int64_t ri = row * a.ldr + gcol + n + e;
-            x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
-            if (rbf) x = round_bf(x);
-          }
-          const int64_t oi = row * a.ldc + gcol + n + e;
-          if (a.C32) ((float*)a.C32)[oi] = x;
-          if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
         }
       }
-    }
-#ifdef USDM_GEMM_TRACE
-    TR(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TR(5);
-#endif
-    if (!is_qkv) return;
-    if (n0 + BN <= 2 * a.qkv_H * a.qkv_D) return;   // no V columns in this tile
-  }
-  // ---- pass 2: outputs whose fast axis is m (transpose_out, V^T of the head-split epilogue); values are final in ct
-  {
-    constexpr int R4 = BM / 4, CPI = NTH / R4, NIT2 = BN / CPI;
-    const int r4 = (tid % R4) * 4, c0 = tid / R4;
-    const int m = m0 + r4;
-    const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
-    if (mv <= 0) return;
-    const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
-    const int b0 = is_qkv ? m / a.qkv_S : 0, s0 = is_qkv ? m - b0 * a.qkv_S : 0;
-#pragma unroll 2
-    for (int it = 0; it < NIT2; ++it) {
-      const int c = c0 + it * CPI, n = n0 + c;
-      if (n >= a.N) break;
-      float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = e < mv ? ct[(r4 + e) * CST + c] : 0.f;
-      if (is_qkv) {
-        const int HD = a.qkv_H * a.qkv_D;
-        if (n < 2 * HD) continue;
-        const int hn = n - 2 * HD, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-        bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
-        if (mv == 4 && s0 + 3 < a.qkv_S && (s0 & 1) == 0) {        // 4 tokens of one sequence: two packed 4-byte stores
-          *(unsigned*)(vrow + s0) = pack_bf2(v[0], v[1]);
-          *(unsigned*)(vrow + s0 + 2) = pack_bf2(v[2], v[3]);
-        } else {
-          for (int e = 0; e < mv; ++e) {
-            const int mm = m + e, b = mm / a.qkv_S, sq = mm - b * a.qkv_S;
-            ((bf16_t*)a.qkv_v)[(((int64_t)b * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + sq] = f2bf(v[e]);
+      for (int u = 0; u < NB; ++u) {
+        const int r = er + (it0 + u) * RPI, m = m0 + r;
+        if (m >= a.M) break;
+        const float4 cv = *(const float4*)(ct + r * CST + ec);
+        float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = a.alpha * v[e] + bv[e];
+          if (rbf) v[e] = round_bf(v[e]);
+        }
+        if (has_res) {
+          v[0] += rres[u].x; v[1] += rres[u].y; v[2] += rres[u].z; v[3] += rres[u].w;
+          if (rbf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
           }
         }
-        continue;
+        const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
+        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
       }
-      for (int e = 0; e < mv; ++e) {
-        const int64_t rw = row + (int64_t)e * a.c_row_mul;
-        float x = v[e];
+      row += NB * rstep;
+    }
+  } else if (nv > 0) {
+    // ragged / unaligned columns (N or ldc not a multiple of 4): scalar accesses, rolled
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+      const int r = er + it * RPI, m = m0 + r;
+      if (m >= a.M) break;
+      const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
+      for (int e = 0; e < nv; ++e) {
+        float x = a.alpha * ct[r * CST + ec + e] + bv[e];
+        if (rbf) x = round_bf(x);
+        x = act_fn(x);
         if (a.residual) {
-          const int64_t ri = rw * a.ldr + gcol + n;
+          const int64_t ri = row * a.ldr + gcol + n + e;
           x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
           if (rbf) x = round_bf(x);
         }
-        const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
+        const int64_t oi = row * a.ldc + gcol + n + e;
         if (a.C32) ((float*)a.C32)[oi] = x;
         if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
       }
     }
   }
+#ifdef USDM_GEMM_TRACE
+  TR(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TR(5);
+#endif
 }
 
 template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2>
@@ -614,32 +695,28 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     USDM_CHECK_ARG(a.N % 32 == 0 && !a.transpose_out && !a.residual && a.ldc % 4 == 0 && a.c_gcol % 8 == 0 && a.epi == USDM_EPI_PLAIN,
                    "usdm_gemm: swiglu needs N%%32==0, ldc%%4==0, row-major output, no residual");
   if (a.epi == USDM_EPI_QKV_HEADS)
-    USDM_CHECK_ARG(a.qkv_q && a.qkv_k && a.qkv_v && a.N == 3 * a.qkv_H * a.qkv_D && a.qkv_S > 0 && a.qkv_Spad >= a.qkv_S &&
+    USDM_CHECK_ARG(a.qkv_q && a.qkv_k && a.qkv_v && a.N == 3 * a.qkv_H * a.qkv_D && (a.qkv_H * a.qkv_D) % 64 == 0 && a.qkv_S > 0 && a.qkv_Spad >= a.qkv_S &&
                        a.qkv_D % 4 == 0 && !a.transpose_out && !a.residual && a.groups == 1 && a.batch == 1,
                    "usdm_gemm: bad qkv epilogue args");
   hipStream_t st = (hipStream_t)stream;
-  // tile heuristic from tools/bench_gemm_tiles.py on MI355X (profiles/r01_gemm_tiles.txt): the kernel is L2->LDS
-  // traffic bound, so the big tile wins once there are >= ~2.5 tiles per CU; mid-size problems with wide N take
-  // 128x64; everything else fills the chip best with 64x64.
+  // tile selection, measured on MI355X (profiles/r01_gemm_tiles.txt, profiles/r01_gemm_ablation.txt)
   const int64_t z = (int64_t)a.groups * a.batch;
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
-  int sel;  // 4: 128x128, 6: 128x64, 5: 64x64 (LDS-DMA variants); 0-3: register-staged variants kept for A/B runs
-  // 128x128 wins when its tiles fill one round (2 workgroups per CU) or many rounds; in between, wave quantisation
-  // makes the small tile faster (profiles/r01_gemm_tiles.txt).
-  // In-situ measurements (tools/stage_times.py, profiles/r01_gemm_ablation.txt): with operands coming from HBM/MALL
-  // rather than a hot L2, the register-staged loaders (two K-steps in flight) beat the single-stage LDS-DMA loaders on
-  // the mid-size shapes of the path; the DMA variant is used where it wins clearly: large single-tap GEMMs.
-  // USDM_GEMM_HEUR=1: the microbenchmark-optimal choice (hot L2) that prefers the LDS-DMA variants; in situ it is
-  // ~2 % slower for the Voicebox layer (weights stream from HBM), so it stays an experiment switch.
-  static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 0;
+  int sel;  // 0-2: register-staged 128x128 / 128x64 / 64x64; 4-6: the same tiles with 2-stage LDS-DMA; 7-11: deeper DMA pipelines
+  // Single-tap GEMMs (Linear layers): chosen from tools/vb_gemm_bench.py (the Voicebox layer's GEMMs over cold weights) and
+  // tools/bench_gemm_tiles.py, see profiles/r01_gemm_ablation.txt.  USDM_GEMM_HEUR=0 restores the register-staged choice.
+  static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 1;
   if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
   else if (heur == 1 && a.taps == 1) {
-    if (t128 >= 400) sel = 4;
-    else if (t128 >= 150 && a.Kc >= 2048) sel = 11;
-    else if (t12864 >= 256 && a.Kc >= 2048) sel = 10;
+    if (t128 >= 640) sel = 4;                                          // many rounds of the big tile
+    else if (a.Kc >= 8192 && t128 >= 128 && t128 <= 256) sel = 11;     // one deep-K tile per CU: 3-stage DMA pipeline
+    else if (a.Kc >= 2048 && t12864 >= 256) sel = 10;                  // deep K, few tiles: 128x64, 3 stages
+    else if (t128 >= 400 && t128 <= 512) sel = 4;                      // exactly one round of 2 workgroups per CU
+    else if (a.N >= 2048 && t12864 >= 768) sel = 6;
     else sel = 5;
   }
+  // multi-tap operands (convolutions): register-staged loaders (the DMA path recomputes the tap row shift per K-step)
   else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;

@@ -30,6 +30,14 @@ __device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
 //     ring is issued BEFORE x is staged / RMS-normalised into LDS, so the prologue hides under HBM latency;
 //   * RW is chosen by the launcher so that the grid is a whole number of workgroups per CU.
 // ---------------------------------------------------------------------------------------------
+#ifdef USDM_GEMV_TRACE
+// debugging aid (tools/gemv_trace.py): per-workgroup phase timestamps (100 MHz wall clock)
+__device__ unsigned long long g_gemv_trace[8192 * 8];
+#define GTR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemv_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GTR(i) do { } while (0)
+#endif
+
 template <int RW, bool GLU, int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
@@ -41,6 +49,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   __shared__ float sv[NWV];
   __shared__ int si[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  GTR(0);
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
   const int nit = Kpad >> 9;
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     for (int j = 0; j < NR; ++j)
       if (u < nit) ring[j][u] = wload(j, u);
 
+  GTR(1);
   // ---- stage x into LDS (optionally fused RMSNorm with HF rounding) while the first ring is in flight
   const bf16_t* xg = (const bf16_t*)a.x;
   if (a.norm_w) {
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     }
   }
   __syncthreads();
+  GTR(2);
 
   // ---- stream: consume ring slot, immediately refill it UNR iterations ahead
   float acc[NR];
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   }
 #pragma unroll
   for (int j = 0; j < NR; ++j) acc[j] = wave_sum(acc[j]);
+  GTR(3);
 
   // ---- epilogue
   if (a.part_val) {  // lm_head: bf16-rounded logits, ban mask, per-block arg-max (ties -> lowest id)
@@ -321,6 +333,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   const int k0 = sp * chunk, k1 = min(ctx, k0 + chunk);
   const int nk = max(0, k1 - k0);
   const bf16_t* qkv = (const bf16_t*)a.qkv;
+  const bf16_t* Kc = (const bf16_t*)a.kcache + (int64_t)kh * a.ctx_max * 128;
+  const bf16_t* Vc = (const bf16_t*)a.vcache + (int64_t)kh * a.ctx_max * 128;
+  // ---- everything that depends only on pos is requested NOW: the first batch of K rows (scores layout) and of V rows
+  // (PV layout) is in flight while q/k are roped; at ~25 keys per split that is the whole split, so the kernel pays one
+  // memory latency instead of three (rope inputs -> K -> V).
+  constexpr int SW = 4, PW = 4;
+  const int j = lane & 7, gk = (wave << 3) + (lane >> 3);  // scores: 8 lanes per key, key slot within a 32-key sweep
+  const int d4 = (tid & 31) * 4, kl = tid >> 5;            // PV: thread = (4 d's, key lane)
+  u32x4 r0[SW], r1[SW];
+  u32x2 rv[PW];
+  if (nk > 0) {
+#pragma unroll
+    for (int w = 0; w < SW; ++w) {
+      const int kk = min(32 * w + gk, nk - 1);
+      const bf16_t* kp = Kc + (int64_t)(k0 + kk) * 128 + j * 16;
+      r0[w] = *(const u32x4*)kp;
+      r1[w] = *(const u32x4*)(kp + 8);
+    }
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+      const int kk = min(8 * w + kl, nk - 1);
+      rv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
+    }
+  }
   // ---- rope q (G heads) and the new k; stash v
   for (int i = tid; i < (G + 1) * 64; i += 256) {
     const int hsel = i >> 6, d = i & 63;
@@ -333,29 +369,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   }
   if (tid < 128) vnew[tid] = bf2f(qkv[(a.Hq + a.Hkv + kh) * 128 + tid]);
   __syncthreads();
-  const bf16_t* Kc = (const bf16_t*)a.kcache + (int64_t)kh * a.ctx_max * 128;
-  const bf16_t* Vc = (const bf16_t*)a.vcache + (int64_t)kh * a.ctx_max * 128;
   if (sp == 0 && tid < 128) {  // designated writer of the new cache row
     ((bf16_t*)a.kcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
     ((bf16_t*)a.vcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
   }
   // ---- scores: 8 lanes per key, 16 d each; the K rows of SW sweeps are requested before any of them is used
   {
-    constexpr int SW = 4;
-    const int j = lane & 7, gk = (wave << 3) + (lane >> 3);  // key slot within a 32-key sweep
     float qr[G][16];
 #pragma unroll
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 16; ++e) qr[h][e] = qs[h][j * 16 + e];
     for (int base = 0; base < nk; base += 32 * SW) {
-      u32x4 r0[SW], r1[SW];
+      if (base > 0) {
 #pragma unroll
-      for (int w = 0; w < SW; ++w) {
-        const int kk = min(base + 32 * w + gk, nk - 1);
-        const bf16_t* kp = Kc + (int64_t)(k0 + kk) * 128 + j * 16;
-        r0[w] = *(const u32x4*)kp;
-        r1[w] = *(const u32x4*)(kp + 8);
+        for (int w = 0; w < SW; ++w) {
+          const int kk = min(base + 32 * w + gk, nk - 1);
+          const bf16_t* kp = Kc + (int64_t)(k0 + kk) * 128 + j * 16;
+          r0[w] = *(const u32x4*)kp;
+          r1[w] = *(const u32x4*)(kp + 8);
+        }
       }
 #pragma unroll
       for (int w = 0; w < SW; ++w) {
@@ -401,19 +434,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   __syncthreads();
   // ---- PV: thread = (4 d's, key lane)
   {
-    const int d4 = (tid & 31) * 4, kl = tid >> 5;
     float acc[G][4];
 #pragma unroll
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
-    constexpr int PW = 4;   // V rows requested together
     for (int base = 0; base < nk; base += 8 * PW) {
-      u32x2 rv[PW];
+      if (base > 0) {
 #pragma unroll
-      for (int w = 0; w < PW; ++w) {
-        const int kk = min(base + 8 * w + kl, nk - 1);
-        rv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
+        for (int w = 0; w < PW; ++w) {
+          const int kk = min(base + 8 * w + kl, nk - 1);
+          rv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
+        }
       }
 #pragma unroll
       for (int w = 0; w < PW; ++w) {
@@ -442,12 +474,64 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     const int h = i >> 7, d = i & 127;
     float s = 0.f;
 #pragma unroll
-    for (int kl = 0; kl < 8; ++kl) s += red[kl][h][d];
+    for (int kl2 = 0; kl2 < 8; ++kl2) s += red[kl2][h][d];
     const int hq = kh * G + h;
-    a.po[((int64_t)hq * NS + sp) * 128 + d] = s;
+    // agent-scope (write-through) stores: the merging workgroup may sit on another XCD, whose L2 is not coherent with ours
+    __hip_atomic_store(a.po + ((int64_t)hq * NS + sp) * 128 + d, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == 0) {
-      a.pm[hq * NS + sp] = nk > 0 ? lmax[h] : -1e30f;
-      a.pl[hq * NS + sp] = nk > 0 ? lsum[h] : 0.f;
+      __hip_atomic_store(a.pm + hq * NS + sp, nk > 0 ? lmax[h] : -1e30f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.pl + hq * NS + sp, nk > 0 ? lsum[h] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (!a.counters) return;   // partials are merged by attn_combine_kernel
+  // ---- fused merge: the workgroup that finishes this kv head last combines the NS partials of its G heads.
+  // No agent-scope fences (an L2 write-back / invalidate per workgroup cost ~30 us per launch): the partials travel
+  // as write-through stores and are read back with agent-scope loads; ordering = every thread waits for its own
+  // stores to be acknowledged, workgroup barrier, then one relaxed increment of the kv head's counter.
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(a.counters + kh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == NS - 1);
+    if (old == NS - 1) __hip_atomic_store(a.counters + kh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  {
+    float* wgt = &sc[0][0];                       // [G][64] merge weights (sc is free now; DA_KMAX >= 64)
+    for (int h = wave; h < G; h += 4) {           // wave per head: NS <= 64 lanes
+      const int hq = kh * G + h;
+      const float mv = lane < NS ? __hip_atomic_load(a.pm + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
+      const float m = wave_max(mv);
+      const float e = lane < NS ? __expf(mv - m) : 0.f;
+      const float l = wave_sum(lane < NS ? __hip_atomic_load(a.pl + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * e : 0.f);
+      wgt[h * 64 + lane] = e;
+      if (lane == 0) lsum[h] = 1.0f / l;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * 128; i += 256) {
+      const int h = i >> 7, d = i & 127;
+      const int hq = kh * G + h;
+      const float* p = a.po + (int64_t)hq * NS * 128 + d;
+      auto ld = [&](int si) { return __hip_atomic_load(p + si * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      float o = 0.f;
+      int s = 0;
+      for (; s + 16 <= NS; s += 16) {             // 16 partials in flight per output; same association as attn_combine_kernel
+        float pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = ld(s + u);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4)
+          o += (pv[u] * wgt[h * 64 + s + u] + pv[u + 1] * wgt[h * 64 + s + u + 1]) +
+               (pv[u + 2] * wgt[h * 64 + s + u + 2] + pv[u + 3] * wgt[h * 64 + s + u + 3]);
+      }
+      for (; s + 4 <= NS; s += 4) {
+        const float a0 = ld(s), a1 = ld(s + 1), a2 = ld(s + 2), a3 = ld(s + 3);
+        o += (a0 * wgt[h * 64 + s] + a1 * wgt[h * 64 + s + 1]) + (a2 * wgt[h * 64 + s + 2] + a3 * wgt[h * 64 + s + 3]);
+      }
+      for (; s < NS; ++s) o += ld(s) * wgt[h * 64 + s];
+      ((bf16_t*)a.out)[hq * 128 + d] = f2bf(o * lsum[h]);
     }
   }
 }
@@ -676,6 +760,12 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   USDM_LAUNCH_CHECK();
   return 0;
 }
+#ifdef USDM_GEMV_TRACE
+extern "C" int usdm_dbg_gemv_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemv_trace), sizeof(unsigned long long) * n);
+}
+#endif
+
 extern "C" int usdm_gemv_nblocks(int32_t N, int32_t act) { return cdiv(N, 16); }
 
 extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
@@ -741,8 +831,10 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);
   else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
   USDM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out);
-  USDM_LAUNCH_CHECK();
+  if (!a.counters) {
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out);
+    USDM_LAUNCH_CHECK();
+  }
   return 0;
 }
 

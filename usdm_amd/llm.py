@@ -247,11 +247,15 @@ class USDMForCausalLM:
         h, qkv, ao, act = self.h_dec, Z(nq), Z(Hq * d), Z(I)
         pm, pl, po = Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS * d, dt=torch.float32)
         part = Z(H, dt=torch.float32) if tp > 1 else None
+        # last-arriver counters of the fused partial merge (self-resetting).  Off by default: measured 11.3-11.6 us per layer
+        # against 5.9 + 4.6 us for the split kernel + merge kernel (profiles/r01_decode_ablation.txt)
+        import os
+        cnt = Z(Hkv, dt=torch.int32) if os.environ.get("USDM_ATTN_FUSED_MERGE", "0") == "1" else None
         for l in range(L):   # h already holds the embedding of the current token (written by usdm_argmax_final)
             w = self.W["layers"][l]
             ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, plan=plan)
             if tp == 1:
                 ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, plan=plan)
             else:

@@ -245,12 +245,12 @@ def rope_cache(qkv, cos, sin, kcache, vcache, *, ld, S, pos0, Hq, Hkv, ctx_max, 
     _go(plan, "usdm_rope_cache", lib.usdm_rope_cache, C_.byref(a))
 
 
-def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, plan=None):
-    _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out)
+def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, plan=None):
+    _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
     a.cos, a.sin, a.kcache, a.vcache = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache)
-    a.pm, a.pl, a.po, a.out = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out)
+    a.pm, a.pl, a.po, a.out, a.counters = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out), _ptr(counters)
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
