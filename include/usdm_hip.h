@@ -237,6 +237,21 @@ int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t np
                       const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd, void* h_out_bf16,
                       usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input) */
 
+/* Sampling twin of usdm_argmax_final: temperature -> top-k -> top-p (HF TemperatureLogitsWarper, TopKLogitsWarper,
+ * TopPLogitsWarper: generate(do_sample=True, top_k, top_p, temperature) of src/inference.py:63-83 with the knobs the demo
+ * exposes, streamlit_demo.py:201-211) and one multinomial draw with Philox4x32-10(seed, counter = *st->step).
+ * logits: f32 [V] of this step with banned ids = -inf (usdm_gemv lm_head mode writes exactly that into y32).
+ * top_k = 0 and top_p = 1 switch the filters off.  Ties at a filter boundary are kept or dropped as a block (HF's
+ * unstable sort picks arbitrarily).  probs_out (optional, [V]) receives the filtered, renormalised distribution. */
+typedef struct usdm_sample_args {
+  const float* logits; int32_t V;
+  float temperature; int32_t top_k; float top_p;
+  uint64_t seed;
+  float* probs_out;
+} usdm_sample_args;
+int usdm_sample_final(const usdm_sample_args* args, const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd,
+                      void* h_out_bf16, usdm_stream_t stream);
+
 /* out[r][:] = table[ids[r]][:] (bf16 rows; ids == NULL -> single row from *next_token) */
 int usdm_embed_rows(const void* table, const int64_t* ids, const int32_t* next_token, int32_t n, int32_t Hd,
                     void* out, usdm_stream_t stream);

@@ -173,3 +173,39 @@ def test_mel_oracle_sanity():
     y = MO.resample(torch.sin(2 * torch.pi * 440 * t), 16000, 22050)
     t2 = torch.arange(y.numel()) / 22050.0
     assert y.numel() == 22050 and (y[200:-200] - torch.sin(2 * torch.pi * 440 * t2)[200:-200]).abs().max() < 2e-2
+
+
+def test_sampling_oracle_matches_hf_warpers():
+    """oracle/sampling_oracle.filtered_probs keeps exactly the ids HF's warpers keep (tie-free inputs) with the same
+    probabilities; the Philox stream is the published Philox4x32-10 (known-answer vector of Random123)."""
+    import torch
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from oracle import sampling_oracle as so
+    g = np.random.default_rng(0)
+    for V, T, k, p in ((1000, 0.7, 50, 0.9), (42003, 1.3, 0, 0.95), (42003, 1.0, 200, 1.0), (517, 0.5, 10, 0.5)):
+        x = (g.standard_normal(V) * 3).astype(np.float32)
+        x[g.integers(0, V, V // 10)] = -np.inf                    # banned ids
+        s = torch.from_numpy(x)[None]
+        ids = torch.zeros(1, 1, dtype=torch.long)
+        s = TemperatureLogitsWarper(T)(ids, s)
+        if k:
+            s = TopKLogitsWarper(k)(ids, s)
+        if p < 1:
+            s = TopPLogitsWarper(p)(ids, s)
+        ref = torch.softmax(s[0].double(), -1).numpy()
+        mine = so.filtered_probs(x, T, k, p)
+        assert ((ref > 0) == (mine > 0)).all(), (V, T, k, p)
+        np.testing.assert_allclose(mine, ref, rtol=2e-6, atol=1e-9)
+    # Random123 known-answer test: philox4x32-10, counter = key = 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    c, kk = [0, 0, 0, 0], [0, 0]
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ kk[0]) & so.M32, p1 & so.M32, ((p0 >> 32) ^ c[3] ^ kk[1]) & so.M32, p0 & so.M32]
+        kk = [(kk[0] + 0x9E3779B9) & so.M32, (kk[1] + 0xBB67AE85) & so.M32]
+    assert c == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert so.philox_uniform(0, 0) == float(((0x6627E8D5 >> 5) << 26) | (0xE169C58D >> 6)) / 2 ** 53
+    # the draw lands in the interval of the returned id
+    tok, pr = so.sample(x, step=7, temperature=0.8, top_k=40, top_p=0.9, seed=123)
+    cs = np.cumsum(pr)
+    u = so.philox_uniform(123, 7)
+    assert (cs[tok - 1] if tok else 0.0) <= u * cs[-1] < cs[tok] and pr[tok] > 0

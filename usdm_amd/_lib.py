@@ -117,6 +117,13 @@ class DecodeState(C.Structure):
     ]
 
 
+class SampleArgs(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("V", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
+        ("seed", C.c_uint64), ("probs_out", C.c_void_p),
+    ]
+
+
 class RopeArgs(C.Structure):
     _fields_ = [
         ("qkv", C.c_void_p), ("ld", C.c_int64), ("S", C.c_int32), ("pos0", C.c_int32), ("Hq", C.c_int32),
@@ -148,7 +155,7 @@ def _selfcheck():
         raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
-                      ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs)):
+                      ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs)):
         n = getattr(lib, f"usdm_sizeof_{name}" if name == "decode_state" else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

@@ -91,6 +91,7 @@ class USDMForCausalLM:
         self.W = None
         self._prefill_plans = {}
         self._decode = None
+        self._decodes = {}
         self._ban_cache = {}
         self.stats = {}
         self.keep_logits = False  # debug/tests: keep the fp32 (bf16-valued) logits of the last step
@@ -177,13 +178,25 @@ class USDMForCausalLM:
         dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
         dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
 
-    def _lm_head_and_pick(self, plan, x, advance_pos, segs):
+    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None):
+        """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
+        sampling=(temperature, top_k, top_p, seed): usdm_sample_final over the ban-masked logits."""
         c = self.cfg
-        if self.keep_logits and self.last_logits is None:
+        want_logits = self.keep_logits or sampling is not None
+        if want_logits and self.last_logits is None:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
-                 y32=self.last_logits if self.keep_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0, plan=plan)
+                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0, plan=plan)
         st = ops.decode_state(self.st_next, self.st_out, self.st_step, self.st_pos, advance_pos=advance_pos)
+        if sampling is not None:
+            if self.tp_path:
+                raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
+            temperature, top_k, top_p, seed = sampling
+            ops.sample_final(self.last_logits, st, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed,
+                             embed=self.W["embed"], h_out=self.h_dec, Hd=c["hidden_size"], plan=plan)
+            plan.hold(st)
+            segs.append(plan)
+            return
         if self.tp_path:
             segs.append(plan)
             segs.append(self._gather_partials)
@@ -195,7 +208,7 @@ class USDMForCausalLM:
         segs.append(plan)
 
     # ------------------------------------------------------------------ plans
-    def _build_prefill(self, S):
+    def _build_prefill(self, S, sampling=None):
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
@@ -233,11 +246,11 @@ class USDMForCausalLM:
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
                 ops.residual_add(h, part, S * H, plan=plan)
-        self._lm_head_and_pick(plan, h[S - 1], False, segs)
+        self._lm_head_and_pick(plan, h[S - 1], False, segs, sampling)
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs, io
 
-    def _build_decode(self):
+    def _build_decode(self, sampling=None):
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
@@ -271,7 +284,7 @@ class USDMForCausalLM:
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
                 ops.residual_add(h, part, H, plan=plan)
-        self._lm_head_and_pick(plan, h, True, segs)
+        self._lm_head_and_pick(plan, h, True, segs, sampling)
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs
 
@@ -302,15 +315,20 @@ class USDMForCausalLM:
 
     @torch.no_grad()
     def generate(self, input_ids=None, max_length=None, do_sample=False, bad_words_ids=None, top_p=1.0, top_k=None,
-                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, **unused):
-        """Greedy generation with the call shape of src/inference.py:63-83.  do_sample=True is accepted only
-        with top_k == 1 (what the reference passes): that is arg-max of the ban-masked logits."""
+                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, seed=0, **unused):
+        """Generation with the call shape of src/inference.py:63-83.  Greedy when do_sample is False or top_k == 1 (what the
+        reference passes: arg-max of the ban-masked logits).  Otherwise temperature / top-k / top-p sampling on the device
+        (usdm_sample_final; `seed` keys its Philox stream — torch's global generator is not consulted)."""
         if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
             raise ValueError("input_ids must be a LongTensor of shape [1, L] (batch 1, as the reference calls it)")
+        sampling = None
         if do_sample and top_k != 1:
-            raise NotImplementedError("sampling other than top_k=1 (== greedy) is outside the reference's inference path")
-        if temperature != 1.0 or top_p != 1.0:
-            raise NotImplementedError("temperature/top_p other than 1.0 are outside the reference's inference path")
+            if not (temperature > 0) or not (0 < top_p <= 1):
+                raise ValueError("temperature must be > 0 and top_p in (0, 1]")
+            sampling = (float(temperature), int(top_k or 0), float(top_p), int(seed))
+        elif temperature != 1.0 or top_p != 1.0:
+            if not do_sample:
+                raise ValueError("temperature / top_p only apply with do_sample=True")
         L0 = input_ids.shape[1]
         if max_new_tokens is None:
             if max_length is None:
@@ -319,17 +337,18 @@ class USDMForCausalLM:
         max_new_tokens = min(max_new_tokens, self.ctx_max - L0, self.max_out)
         if max_new_tokens <= 0:
             return input_ids.clone()
-        if L0 not in self._prefill_plans:
-            self._prefill_plans[L0] = self._build_prefill(L0)
-        segs, io = self._prefill_plans[L0]
+        if (L0, sampling) not in self._prefill_plans:
+            self._prefill_plans[(L0, sampling)] = self._build_prefill(L0, sampling)
+        segs, io = self._prefill_plans[(L0, sampling)]
         io["ids"].copy_(input_ids[0])
         self.ban.copy_(self._ban_mask(bad_words_ids))
         self.st_pos.fill_(L0)
         self.st_step.zero_()
         self._run_segs(segs)  # prefill + first token
-        if self._decode is None:
-            dsegs = self._build_decode()
-            self._decode = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
+        if sampling not in self._decodes:
+            dsegs = self._build_decode(sampling)
+            self._decodes[sampling] = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
+        self._decode = self._decodes[sampling]
         eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
         produced, done, chunk = 1, False, 8
         toks = []

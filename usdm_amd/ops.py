@@ -8,7 +8,7 @@ import ctypes as C_
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, AttnArgs, AttnDecodeArgs, DecodeState, GemmArgs, GemvArgs, NormArgs, RopeArgs, SnakeArgs,
+from ._lib import (BF16, F32, AttnArgs, AttnDecodeArgs, DecodeState, GemmArgs, GemvArgs, NormArgs, RopeArgs, SampleArgs, SnakeArgs,
                    VbInputArgs, VbSolverArgs, check, lib)
 
 
@@ -230,6 +230,15 @@ def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, p
     _need_cuda(part_val, part_idx, embed, h_out)
     _go(plan, "usdm_argmax_final", lib.usdm_argmax_final, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st),
         _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
+
+
+def sample_final(logits, st, *, temperature=1.0, top_k=0, top_p=1.0, seed=0, probs_out=None, embed=None, h_out=None, Hd=0, plan=None):
+    """usdm_sample_final: temperature / top-k / top-p sampling of one token from ban-masked f32 logits."""
+    _need_cuda(logits, probs_out, embed, h_out)
+    a = SampleArgs()
+    a.logits, a.V, a.temperature, a.top_k, a.top_p = _ptr(logits), logits.numel(), temperature, top_k, top_p
+    a.seed, a.probs_out = seed, _ptr(probs_out)
+    _go(plan, "usdm_sample_final", lib.usdm_sample_final, C_.byref(a), C_.byref(st), _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 
 def embed_rows(table, out, *, Hd, ids=None, next_token=None, n=1, plan=None):
