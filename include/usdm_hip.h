@@ -219,6 +219,10 @@ typedef struct usdm_gemv_args {
   void* y16; float* y32;
   const uint8_t* ban; float* part_val; int32_t* part_idx;
   int32_t idx_offset; /* added to the row index stored in part_idx (vocab-parallel shards) */
+  /* tensor-parallel decode: the all-reduced f32 partial sum of the previous row-parallel projection is folded in here
+   * instead of a separate residual-add launch: x' = bf16(x + bf16(x_delta)) is what gets normalised / multiplied, and
+   * workgroup 0 writes x' to x_out (a DIFFERENT buffer than x: other workgroups are still reading x) */
+  const float* x_delta; void* x_out;
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */

@@ -107,6 +107,7 @@ class GemvArgs(C.Structure):
         ("act", C.c_int32), ("round_bf16", C.c_int32),
         ("residual", C.c_void_p), ("y16", C.c_void_p), ("y32", C.c_void_p),
         ("ban", C.c_void_p), ("part_val", C.c_void_p), ("part_idx", C.c_void_p), ("idx_offset", C.c_int32),
+        ("x_delta", C.c_void_p), ("x_out", C.c_void_p),
     ]
 
 

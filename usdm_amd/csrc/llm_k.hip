@@ -86,10 +86,24 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   GTR(1);
   // ---- stage x into LDS (optionally fused RMSNorm with HF rounding) while the first ring is in flight
   const bf16_t* xg = (const bf16_t*)a.x;
+  // 8 consecutive elements of the input vector; with x_delta the pending residual add of the tensor-parallel path is applied
+  // on the fly (HF rounding: bf16(h + bf16(delta))) and workgroup 0 publishes the updated residual stream
+  auto ldx = [&](int i, bool publish) -> u32x4 {
+    u32x4 v = *(const u32x4*)(xg + i);
+    if (a.x_delta) {
+      const float4 d0 = *(const float4*)(a.x_delta + i), d1 = *(const float4*)(a.x_delta + i + 4);
+      const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = pack_bf2(bf2f(v[e] & 0xffff) + round_bf(dl[2 * e]), bf2f(v[e] >> 16) + round_bf(dl[2 * e + 1]));
+      if (publish && a.x_out && blockIdx.x == 0) *(u32x4*)((bf16_t*)a.x_out + i) = v;
+    }
+    return v;
+  };
   if (a.norm_w) {
     float ss = 0.f;
     for (int i = tid * 8; i < K; i += NTH * 8) {
-      const u32x4 v = *(const u32x4*)(xg + i);
+      const u32x4 v = ldx(i, false);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = bf2f(v[e] & 0xffff), hi = bf2f(v[e] >> 16);
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     for (int i = tid * 8; i < Kpad; i += NTH * 8) {
       u32x4 o = {0, 0, 0, 0};
       if (i < K) {
-        const u32x4 v = *(const u32x4*)(xg + i);
+        const u32x4 v = ldx(i, true);
         const float4 g0 = *(const float4*)(a.norm_w + i), g1 = *(const float4*)(a.norm_w + i + 4);
         const float gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   } else {
     for (int i = tid * 8; i < Kpad; i += NTH * 8) {
       u32x4 v = {0, 0, 0, 0};
-      if (i < K) v = *(const u32x4*)(xg + i);
+      if (i < K) v = ldx(i, true);
       *(u32x4*)(xs + i) = v;
     }
   }
@@ -726,6 +740,7 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.y16 || a.y32 || a.part_val, "usdm_gemv: no output");
   USDM_CHECK_ARG(!a.part_val || (a.part_idx && !glu), "usdm_gemv: part_idx missing / lm_head mode is not GLU");
   USDM_CHECK_ARG(!a.norm_w || a.K % 8 == 0, "usdm_gemv: K");
+  USDM_CHECK_ARG(!a.x_out || (a.x_delta && a.x_out != a.x), "usdm_gemv: x_out needs x_delta and must not alias x");
   const int nout = glu ? a.N / 2 : a.N;
   const int Kpad = (a.K + 511) & ~511;
   hipStream_t st = (hipStream_t)stream;

@@ -178,7 +178,7 @@ class USDMForCausalLM:
         dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
         dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
 
-    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None):
+    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None):
         """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
         sampling=(temperature, top_k, top_p, seed): usdm_sample_final over the ban-masked logits."""
         c = self.cfg
@@ -186,7 +186,8 @@ class USDMForCausalLM:
         if want_logits and self.last_logits is None:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
-                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0, plan=plan)
+                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0,
+                 x_delta=x_delta, plan=plan)
         st = ops.decode_state(self.st_next, self.st_out, self.st_step, self.st_pos, advance_pos=advance_pos)
         if sampling is not None:
             if self.tp_path:
@@ -264,9 +265,24 @@ class USDMForCausalLM:
         # against 5.9 + 4.6 us for the split kernel + merge kernel (profiles/r01_decode_ablation.txt)
         import os
         cnt = Z(Hkv, dt=torch.int32) if os.environ.get("USDM_ATTN_FUSED_MERGE", "0") == "1" else None
+        # Tensor-parallel path: the residual add that follows each all-reduce is folded into the NEXT GEMV's prologue
+        # (usdm_gemv x_delta / x_out) instead of a usdm_residual_add launch; the residual stream ping-pongs between two
+        # buffers because workgroup 0 publishes the updated stream while the others still read the old one.
+        h_alt = Z(H) if tp > 1 else None
+        fuse_res = tp > 1 and os.environ.get("USDM_TP_FUSED_RESIDUAL", "1") == "1"
+        pend = None   # f32 partial (already all-reduced) not yet added to the residual stream
+        part2 = Z(H, dt=torch.float32) if tp > 1 else None
+
+        def flip(cur):
+            return h_alt if cur is self.h_dec else self.h_dec
+
         for l in range(L):   # h already holds the embedding of the current token (written by usdm_argmax_final)
             w = self.W["layers"][l]
-            ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
+            if pend is not None:
+                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, x_delta=pend, x_out=flip(h), plan=plan)
+                h, pend = flip(h), None
+            else:
+                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
                             ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, plan=plan)
             if tp == 1:
@@ -275,16 +291,30 @@ class USDMForCausalLM:
                 ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, plan=plan)
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
-                ops.residual_add(h, part, H, plan=plan)
-            ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, plan=plan)
+                if fuse_res:
+                    pend = part
+                else:
+                    ops.residual_add(h, part, H, plan=plan)
+            if pend is not None:
+                ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, x_delta=pend,
+                         x_out=flip(h), plan=plan)
+                h, pend = flip(h), None
+            else:
+                ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, plan=plan)
             if tp == 1:
                 ops.gemv(w["down"], act, N=H, K=I, residual=h, y16=h, plan=plan)
             else:
-                ops.gemv(w["down"], act, N=H, K=I, round_bf16=False, y32=part, plan=plan)
-                segs += [plan, (lambda t=part: self._all_reduce(t))]
+                ops.gemv(w["down"], act, N=H, K=I, round_bf16=False, y32=part2, plan=plan)
+                segs += [plan, (lambda t=part2: self._all_reduce(t))]
                 plan = ops.Plan()
-                ops.residual_add(h, part, H, plan=plan)
-        self._lm_head_and_pick(plan, h, True, segs, sampling)
+                if fuse_res:
+                    pend = part2
+                else:
+                    ops.residual_add(h, part2, H, plan=plan)
+        if pend is not None:   # the last down-projection's sum goes into the final norm + lm_head
+            self._lm_head_and_pick(plan, h, True, segs, sampling, x_delta=pend)
+        else:
+            self._lm_head_and_pick(plan, h, True, segs, sampling)
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs
 

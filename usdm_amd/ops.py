@@ -207,15 +207,18 @@ def process_unit(units, rep, hop):
 
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
-         ban=None, part_val=None, part_idx=None, idx_offset=0, plan=None):
+         ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, plan=None):
     """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h)."""
-    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx)
+    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out)
+    if x_out is not None and x_out.data_ptr() == x.data_ptr():
+        raise ValueError("usdm_gemv: x_out must not alias x")
     a = GemvArgs()
     a.W, a.ldw, a.N, a.K = _ptr(W), (ldw if ldw is not None else K), N, K
     a.x, a.norm_w, a.eps = _ptr(x), _ptr(norm_w), eps
     a.act, a.round_bf16 = act, int(round_bf16)
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
+    a.x_delta, a.x_out = _ptr(x_delta), _ptr(x_out)
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
 
 
