@@ -18,6 +18,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int KT = 64;  // keys per tile
 
+#ifdef USDM_ATTN_TRACE
+// debugging aid (tools/attn_trace.py): cycles per phase summed over the key tiles, wave 0 lane 0 of every workgroup
+__device__ unsigned long long g_attn_trace[4096 * 8];
+#define ATR_T() __builtin_readcyclecounter()
+#define ATR_ADD(i, t0) do { const unsigned long long t1_ = ATR_T(); atr[i] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define ATR_T() 0ull
+#define ATR_ADD(i, t0) do { } while (0)
+#endif
+
 template <int DH, int MODE, int NW>  // MODE 0: bidirectional + ALiBi + key-length mask ; 1: causal ; NW waves x 32 queries
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
   constexpr int NT = NW * 64;   // threads
@@ -110,9 +120,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
 
   // two LDS stages, one barrier per key tile: tile kt+1 is written to the other stage and tile kt+2 is
   // in flight from HBM/L2 while tile kt is multiplied
+  unsigned long long atr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tph = ATR_T();
+  const unsigned long long tstart = tph;
   if (ntiles > 0) { load_tile(0); store_tile(0); }
   if (ntiles > 1) load_tile(1);
   __syncthreads();
+  ATR_ADD(0, tph);
   for (int kt = 0; kt < ntiles; ++kt) {
     const char* sK = smem + (kt & 1) * STAGE;
     const char* sV = sK + KT * KROW;
@@ -132,6 +146,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
         sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
       }
     }
+    ATR_ADD(1, tph);
     // ---- bias, mask, online softmax (log2 domain).  VALU-lean: the key position of register r is a compile-time
     // constant plus a per-lane offset, masks are applied only on the (wave-uniform) tiles that need them.
     const int kbase = kt * KT + 4 * lh;                       // kpos(u,r) = kbase + 32u + (r&3) + 8(r>>2)
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
     }
 
+    ATR_ADD(2, tph);
     // ---- O^T += V^T . P^T   (P^T taken from the accumulator registers as the B operand)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -205,10 +221,23 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[t], 0, 0, 0);
         }
       }
+    ATR_ADD(3, tph);
     if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
     if (kt + 2 < ntiles) load_tile(kt + 2);
+    ATR_ADD(4, tph);
     __syncthreads();
+    ATR_ADD(5, tph);
   }
+#ifdef USDM_ATTN_TRACE
+  if (tid == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 4096) {
+      for (int i = 0; i < 6; ++i) g_attn_trace[wg * 8 + i] = atr[i];
+      g_attn_trace[wg * 8 + 6] = ATR_T() - tstart;
+      g_attn_trace[wg * 8 + 7] = ntiles;
+    }
+  }
+#endif
 
   // ---- normalise and store O[q][h*DH + d] (bf16)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -229,6 +258,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
   }
 }
 }  // namespace
+
+#ifdef USDM_ATTN_TRACE
+extern "C" int usdm_dbg_attn_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(pa && pa->q && pa->k && pa->vt && pa->o, "usdm_attention: null args");

@@ -15,6 +15,21 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
   if (row >= a.rows) return;
   const int npieces = a.C >> 2;
   float4 v[NP];
+  // gamma / beta do not depend on the row statistics: requested together with the row so that the kernel pays one memory
+  // latency, not two (NP <= 5 only: the wide instantiations would spill)
+  constexpr bool PRE = NP <= 5;
+  float4 gpre[PRE ? NP : 1], bpre[PRE ? NP : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int idx = p * 64 + lane;
+      gpre[p] = make_float4(0.f, 0.f, 0.f, 0.f); bpre[p] = gpre[p];
+      if (idx < npieces) {
+        gpre[p] = *(const float4*)(a.gamma + idx * 4);
+        if (a.beta) bpre[p] = *(const float4*)(a.beta + idx * 4);
+      }
+    }
+  }
   bool zero_row = false;
   if (a.valid_len) {
     const int b = row / a.rows_per_batch, s = row - b * a.rows_per_batch;
@@ -72,9 +87,13 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
   for (int p = 0; p < NP; ++p) {
     const int idx = p * 64 + lane;
     if (idx >= npieces) continue;
-    const float4 gm = *(const float4*)(a.gamma + idx * 4);
-    float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
+    float4 gm, bt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PRE) {
+      gm = gpre[p]; bt = bpre[p];
+    } else {
+      gm = *(const float4*)(a.gamma + idx * 4);
+      if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
+    }
     float y[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
     const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
