@@ -227,6 +227,16 @@ typedef struct usdm_gemv_args {
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
 
+/* Batched decode: the same GEMV over nb <= 4 input vectors, weights streamed once per step.
+ * g holds item 0's pointers; item b is at + b * stride.  Per item the arithmetic is that of usdm_gemv, bit for bit. */
+typedef struct usdm_gemv_batch_args {
+  usdm_gemv_args g;          /* x_delta / x_out must be NULL */
+  int32_t nb;
+  int64_t x_bs, y_bs, res_bs; /* element strides between items of x, y16 / y32, residual */
+  int32_t part_bs;            /* element stride between items of part_val / part_idx (>= usdm_gemv_nblocks) */
+} usdm_gemv_batch_args;
+int usdm_gemv_batch(const usdm_gemv_batch_args* args, usdm_stream_t stream);
+
 /* Device-resident greedy-decode state so that a decode step is replayable as one hipGraph. */
 typedef struct usdm_decode_state {
   int32_t* next_token;  /* [1] token fed to the next step                     */
@@ -234,12 +244,15 @@ typedef struct usdm_decode_state {
   int32_t* step;        /* [1] number of generated tokens so far              */
   int32_t* pos;         /* [1] number of tokens in the KV cache               */
   int32_t max_out, id_offset, advance_pos;
+  int32_t batch;        /* batched decode: 0 or 1 = single; else arrays of `batch` items: next_token[b], step[b], pos[b],
+                           out_tokens[b][max_out] */
 } usdm_decode_state;
 /* arg-max over the per-block partials (ties -> lowest id = torch.argmax on the masked logits; with
  * do_sample=True, top_k=1 the reference samples among exact ties, of which this is one outcome). */
 int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
                       const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd, void* h_out_bf16,
-                      usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input) */
+                      usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input);
+                                                 batched state: part_val/part_idx are [batch][nparts], h_out [batch][Hd] */
 
 /* Sampling twin of usdm_argmax_final: temperature -> top-k -> top-p (HF TemperatureLogitsWarper, TopKLogitsWarper,
  * TopPLogitsWarper: generate(do_sample=True, top_k, top_p, temperature) of src/inference.py:63-83 with the knobs the demo
@@ -282,6 +295,9 @@ typedef struct usdm_attn_decode_args {
   void* out;
   int32_t* counters; /* [Hkv] zero-initialised once, self-resetting: when given (NS > 1) the workgroup that finishes a
                         kv head last merges its NS partials itself and no separate combine kernel is launched */
+  /* batched decode: `batch` sequences in one launch (0 or 1 = single).  Item b reads pos[b], qkv + b*qkv_bs, caches +
+   * b*cache_bs, writes out + b*out_bs (element strides); scratch is [batch][Hq][NS]...; counters [batch][Hkv]. NS > 1. */
+  int32_t batch; int64_t qkv_bs, out_bs, cache_bs;
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

@@ -111,10 +111,16 @@ class GemvArgs(C.Structure):
     ]
 
 
+class GemvBatchArgs(C.Structure):
+    _fields_ = [
+        ("g", GemvArgs), ("nb", C.c_int32), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("res_bs", C.c_int64), ("part_bs", C.c_int32),
+    ]
+
+
 class DecodeState(C.Structure):
     _fields_ = [
         ("next_token", C.c_void_p), ("out_tokens", C.c_void_p), ("step", C.c_void_p), ("pos", C.c_void_p),
-        ("max_out", C.c_int32), ("id_offset", C.c_int32), ("advance_pos", C.c_int32),
+        ("max_out", C.c_int32), ("id_offset", C.c_int32), ("advance_pos", C.c_int32), ("batch", C.c_int32),
     ]
 
 
@@ -141,6 +147,7 @@ class AttnDecodeArgs(C.Structure):
         ("cos", C.c_void_p), ("sin", C.c_void_p),
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
         ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
+        ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64),
     ]
 
 
@@ -156,7 +163,8 @@ def _selfcheck():
         raise ImportError(f"ABI mismatch: usdm_gemm_args is {n} bytes in the library, {C.sizeof(GemmArgs)} in Python")
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
-                      ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs)):
+                      ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs),
+                      ("gemv_batch", GemvBatchArgs)):
         n = getattr(lib, f"usdm_sizeof_{name}" if name == "decode_state" else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

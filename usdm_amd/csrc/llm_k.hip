@@ -246,6 +246,8 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int s_tok;
+  const int b = blockIdx.x;   // sequence of a batched step (grid = 1 when single)
+  pv += (int64_t)b * nparts; pi += (int64_t)b * nparts;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -265,17 +267,17 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
   }
   if (threadIdx.x == 0) {
     const int tok = si[0] + st.id_offset;
-    const int step = *st.step;
-    *st.next_token = tok;
-    if (step < st.max_out) st.out_tokens[step] = tok;
-    *st.step = step + 1;
-    if (st.advance_pos) *st.pos = *st.pos + 1;
+    const int step = st.step[b];
+    st.next_token[b] = tok;
+    if (step < st.max_out) st.out_tokens[(int64_t)b * st.max_out + step] = tok;
+    st.step[b] = step + 1;
+    if (st.advance_pos) st.pos[b] = st.pos[b] + 1;
     s_tok = tok;
   }
   if (E) {  // fused nn.Embedding lookup of the token the next decode step consumes
     __syncthreads();
     const u32x4* src = (const u32x4*)(E + (int64_t)s_tok * Hd);
-    u32x4* dst = (u32x4*)h_out;
+    u32x4* dst = (u32x4*)(h_out + (int64_t)b * Hd);
     for (int i = threadIdx.x; i < Hd / 8; i += 256) dst[i] = src[i];
   }
 }
@@ -340,15 +342,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   __shared__ float red[8][G][128];
   __shared__ float lsum[G], lmax[G];
   const int kh = blockIdx.x, sp = blockIdx.y, NS = gridDim.y;
+  const int bi = blockIdx.z;                      // sequence of a batched decode step (0 when single)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pos = *a.pos;
+  const int pos = a.pos[bi];
   const int ctx = pos + 1;
   const int chunk = (ctx + NS - 1) / NS;
   const int k0 = sp * chunk, k1 = min(ctx, k0 + chunk);
   const int nk = max(0, k1 - k0);
-  const bf16_t* qkv = (const bf16_t*)a.qkv;
-  const bf16_t* Kc = (const bf16_t*)a.kcache + (int64_t)kh * a.ctx_max * 128;
-  const bf16_t* Vc = (const bf16_t*)a.vcache + (int64_t)kh * a.ctx_max * 128;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + (int64_t)bi * a.qkv_bs;
+  bf16_t* kcache_b = (bf16_t*)a.kcache + (int64_t)bi * a.cache_bs;
+  bf16_t* vcache_b = (bf16_t*)a.vcache + (int64_t)bi * a.cache_bs;
+  const bf16_t* Kc = kcache_b + (int64_t)kh * a.ctx_max * 128;
+  const bf16_t* Vc = vcache_b + (int64_t)kh * a.ctx_max * 128;
+  float* pm_b = a.pm + (int64_t)bi * a.Hq * NS;
+  float* pl_b = a.pl + (int64_t)bi * a.Hq * NS;
+  float* po_b = a.po + (int64_t)bi * a.Hq * NS * 128;
+  bf16_t* out_b = (bf16_t*)a.out + (int64_t)bi * a.out_bs;
   // ---- everything that depends only on pos is requested NOW: the first batch of K rows (scores layout) and of V rows
   // (PV layout) is in flight while q/k are roped; at ~25 keys per split that is the whole split, so the kernel pays one
   // memory latency instead of three (rope inputs -> K -> V).
@@ -384,8 +393,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   if (tid < 128) vnew[tid] = bf2f(qkv[(a.Hq + a.Hkv + kh) * 128 + tid]);
   __syncthreads();
   if (sp == 0 && tid < 128) {  // designated writer of the new cache row
-    ((bf16_t*)a.kcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
-    ((bf16_t*)a.vcache)[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
+    kcache_b[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(knew[tid]);
+    vcache_b[((int64_t)kh * a.ctx_max + pos) * 128 + tid] = f2bf(vnew[tid]);
   }
   // ---- scores: 8 lanes per key, 16 d each; the K rows of SW sweeps are requested before any of them is used
   {
@@ -491,10 +500,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     for (int kl2 = 0; kl2 < 8; ++kl2) s += red[kl2][h][d];
     const int hq = kh * G + h;
     // agent-scope (write-through) stores: the merging workgroup may sit on another XCD, whose L2 is not coherent with ours
-    __hip_atomic_store(a.po + ((int64_t)hq * NS + sp) * 128 + d, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(po_b + ((int64_t)hq * NS + sp) * 128 + d, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == 0) {
-      __hip_atomic_store(a.pm + hq * NS + sp, nk > 0 ? lmax[h] : -1e30f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.pl + hq * NS + sp, nk > 0 ? lsum[h] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pm_b + hq * NS + sp, nk > 0 ? lmax[h] : -1e30f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pl_b + hq * NS + sp, nk > 0 ? lsum[h] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (!a.counters) return;   // partials are merged by attn_combine_kernel
@@ -506,9 +515,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const int old = __hip_atomic_fetch_add(a.counters + kh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_fetch_add(a.counters + bi * a.Hkv + kh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (old == NS - 1);
-    if (old == NS - 1) __hip_atomic_store(a.counters + kh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (old == NS - 1) __hip_atomic_store(a.counters + bi * a.Hkv + kh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
   __syncthreads();
   if (!s_last) return;
@@ -516,10 +525,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     float* wgt = &sc[0][0];                       // [G][64] merge weights (sc is free now; DA_KMAX >= 64)
     for (int h = wave; h < G; h += 4) {           // wave per head: NS <= 64 lanes
       const int hq = kh * G + h;
-      const float mv = lane < NS ? __hip_atomic_load(a.pm + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
+      const float mv = lane < NS ? __hip_atomic_load(pm_b + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
       const float m = wave_max(mv);
       const float e = lane < NS ? __expf(mv - m) : 0.f;
-      const float l = wave_sum(lane < NS ? __hip_atomic_load(a.pl + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * e : 0.f);
+      const float l = wave_sum(lane < NS ? __hip_atomic_load(pl_b + hq * NS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * e : 0.f);
       wgt[h * 64 + lane] = e;
       if (lane == 0) lsum[h] = 1.0f / l;
     }
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     for (int i = tid; i < G * 128; i += 256) {
       const int h = i >> 7, d = i & 127;
       const int hq = kh * G + h;
-      const float* p = a.po + (int64_t)hq * NS * 128 + d;
+      const float* p = po_b + (int64_t)hq * NS * 128 + d;
       auto ld = [&](int si) { return __hip_atomic_load(p + si * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
       float o = 0.f;
       int s = 0;
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
         o += (a0 * wgt[h * 64 + s] + a1 * wgt[h * 64 + s + 1]) + (a2 * wgt[h * 64 + s + 2] + a3 * wgt[h * 64 + s + 3]);
       }
       for (; s < NS; ++s) o += ld(s) * wgt[h * 64 + s];
-      ((bf16_t*)a.out)[hq * 128 + d] = f2bf(o * lsum[h]);
+      out_b[hq * 128 + d] = f2bf(o * lsum[h]);
     }
   }
 }
@@ -699,10 +708,13 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const usdm_attn_deco
   }
 }
 
-__global__ __launch_bounds__(128) void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out) {
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out,
+                                                           int64_t out_bs) {
   __shared__ float w[64];
   __shared__ float linv;
   const int hq = blockIdx.x, d = threadIdx.x;  // 128 threads
+  const int bi = blockIdx.y, Hq = gridDim.x;   // sequence of a batched step
+  pm += (int64_t)bi * Hq * NS; pl += (int64_t)bi * Hq * NS; po += (int64_t)bi * Hq * NS * 128; out += (int64_t)bi * out_bs;
   if (d < 64) {
     const float mv = d < NS ? pm[hq * NS + d] : -1e30f;
     const float m = wave_max(mv);
@@ -789,7 +801,8 @@ extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx,
   USDM_CHECK_ARG(part_val && part_idx && nparts > 0 && st && st->next_token && st->out_tokens && st->step && st->pos,
                  "usdm_argmax_final: bad args");
   USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_argmax_final: embedding output missing");
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st,
+  USDM_CHECK_ARG(st->batch >= 0 && st->batch <= 64, "usdm_argmax_final: batch");
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(st->batch > 1 ? st->batch : 1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st,
                      (const bf16_t*)embed_table, Hd, (bf16_t*)h_out);
   USDM_LAUNCH_CHECK();
   return 0;
@@ -819,6 +832,8 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   USDM_CHECK_ARG(pa->NS == 1 || (pa->pm && pa->pl && pa->po), "usdm_attn_decode: partial buffers missing");
   const usdm_attn_decode_args& a = *pa;
   USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0 && a.NS <= 64, "usdm_attn_decode: heads / NS (<= 64)");
+  USDM_CHECK_ARG(a.batch <= 1 || (a.NS > 1 && a.batch <= 64 && a.qkv_bs > 0 && a.out_bs > 0 && a.cache_bs > 0),
+                 "usdm_attn_decode: batched form needs NS > 1 and the three strides");
   USDM_CHECK_ARG(a.NS == 1 || cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
   const int G = a.Hq / a.Hkv;
   hipStream_t st = (hipStream_t)stream;
@@ -840,14 +855,15 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
     USDM_LAUNCH_CHECK();
     return 0;
   }
-  dim3 grid(a.Hkv, a.NS);
+  const int nbatch = a.batch > 1 ? a.batch : 1;
+  dim3 grid(a.Hkv, a.NS, nbatch);
   if (G == 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, st, a);
   else if (G == 2) hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), 0, st, a);
   else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);
   else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
   USDM_LAUNCH_CHECK();
   if (!a.counters) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq, nbatch), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out, a.out_bs);
     USDM_LAUNCH_CHECK();
   }
   return 0;

@@ -92,6 +92,7 @@ class USDMForCausalLM:
         self._prefill_plans = {}
         self._decode = None
         self._decodes = {}
+        self._batches = {}
         self._ban_cache = {}
         self.stats = {}
         self.keep_logits = False  # debug/tests: keep the fp32 (bf16-valued) logits of the last step
@@ -178,17 +179,18 @@ class USDMForCausalLM:
         dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
         dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
 
-    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None):
+    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None, slot=None):
         """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
         sampling=(temperature, top_k, top_p, seed): usdm_sample_final over the ban-masked logits."""
         c = self.cfg
+        sl = slot or self   # where the picked token, the decode state and the next input row live (self = the single sequence)
         want_logits = self.keep_logits or sampling is not None
         if want_logits and self.last_logits is None:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
-                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=self.part_val_loc, part_idx=self.part_idx_loc, idx_offset=self.v0,
+                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=sl.part_val_loc, part_idx=sl.part_idx_loc, idx_offset=self.v0,
                  x_delta=x_delta, plan=plan)
-        st = ops.decode_state(self.st_next, self.st_out, self.st_step, self.st_pos, advance_pos=advance_pos)
+        st = ops.decode_state(sl.st_next, sl.st_out, sl.st_step, sl.st_pos, advance_pos=advance_pos)
         if sampling is not None:
             if self.tp_path:
                 raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
@@ -203,13 +205,13 @@ class USDMForCausalLM:
             segs.append(self._gather_partials)
             plan = ops.Plan()
         # the picked token's embedding row is written straight into the decode step's input vector
-        ops.argmax_final(self.part_val, self.part_idx, self.nparts * self.tp_size, st, embed=self.W["embed"], h_out=self.h_dec,
+        ops.argmax_final(sl.part_val, sl.part_idx, self.nparts * self.tp_size, st, embed=self.W["embed"], h_out=sl.h_dec,
                          Hd=c["hidden_size"], plan=plan)
         plan.hold(st)
         segs.append(plan)
 
     # ------------------------------------------------------------------ plans
-    def _build_prefill(self, S, sampling=None):
+    def _build_prefill(self, S, sampling=None, slot=None):
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
@@ -226,9 +228,9 @@ class USDMForCausalLM:
             w = self.W["layers"][l]
             ops.norm(h, w["ln1"], None, rows=S, C=H, eps=c["rms_norm_eps"], rms=True, round_bf16=True, out16=xn, plan=plan)
             ops.gemm(xn, w["qkv"], M=S, N=nq, Kc=H, out16=qkv, plan=plan)
-            ops.rope_cache(qkv, self.cos, self.sin, self.kcache[l], self.vcache[l], ld=nq, S=S, pos0=0, Hq=Hq, Hkv=Hkv,
+            ops.rope_cache(qkv, self.cos, self.sin, (slot or self).kcache[l], (slot or self).vcache[l], ld=nq, S=S, pos0=0, Hq=Hq, Hkv=Hkv,
                            ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=vt, vt_ld=Spad, plan=plan)
-            ops.attention(qkv, self.kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
+            ops.attention(qkv, (slot or self).kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
                           q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d), v_strides=(0, d * Spad, Spad),
                           o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
             if tp == 1:
@@ -247,7 +249,7 @@ class USDMForCausalLM:
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
                 ops.residual_add(h, part, S * H, plan=plan)
-        self._lm_head_and_pick(plan, h[S - 1], False, segs, sampling)
+        self._lm_head_and_pick(plan, h[S - 1], False, segs, sampling, slot=slot)
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs, io
 
@@ -325,6 +327,118 @@ class USDMForCausalLM:
                 s.run()
             else:
                 s()
+
+    # ------------------------------------------------------------------ batched decode
+    class _Slot:
+        """Views of the batch buffers that stand in for the single-sequence attributes during a per-item prefill."""
+
+    def _batch_buffers(self, B):
+        if B in self._batches:
+            return self._batches[B]
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        L, d, H = c["num_hidden_layers"], c["head_dim"], c["hidden_size"]
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        bb = dict(kc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
+                  vc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
+                  nxt=i32(B), step=i32(B), pos=i32(B), out=i32(B, self.max_out), h=torch.zeros(B, H, dtype=bf, device=dev),
+                  pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill={}, decode=None)
+        slots = []
+        for b in range(B):
+            sl = self._Slot()
+            sl.kcache, sl.vcache = bb["kc"][b], bb["vc"][b]
+            sl.st_next, sl.st_step, sl.st_pos, sl.st_out = bb["nxt"][b:b + 1], bb["step"][b:b + 1], bb["pos"][b:b + 1], bb["out"][b]
+            sl.h_dec = bb["h"][b]
+            sl.part_val = sl.part_val_loc = bb["pv"][b]
+            sl.part_idx = sl.part_idx_loc = bb["pi"][b]
+            slots.append(sl)
+        bb["slots"] = slots
+        self._batches[B] = bb
+        return bb
+
+    def _build_decode_batch(self, B):
+        """One decode step of B sequences: weights streamed once (usdm_gemv_batch), attention / arg-max batched over items."""
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
+        Hq, Hkv, I = self.Hq, self.Hkv, self.I
+        nq = (Hq + 2 * Hkv) * d
+        bb = self._batch_buffers(B)
+        plan = ops.Plan()
+        Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        h, qkv, ao, act = bb["h"], Z(B, nq), Z(B, Hq * d), Z(B, I)
+        NS = max(2, self.NS)
+        pm, pl, po = Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS * d, dt=torch.float32)
+        cache_bs = L * Hkv * self.ctx_max * d
+        for l in range(L):
+            w = self.W["layers"][l]
+            ops.gemv_batch(w["qkv"], h, nb=B, N=nq, K=H, x_bs=H, y_bs=nq, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
+            ops.attn_decode(qkv, bb["pos"], self.cos, self.sin, bb["kc"][0, l], bb["vc"][0, l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
+                            ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, plan=plan)
+            ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
+            ops.gemv_batch(w["gu"], h, nb=B, N=2 * I, K=H, x_bs=H, y_bs=I, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU,
+                           y16=act, plan=plan)
+            ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
+        ops.gemv_batch(self.W["lm_head"], h, nb=B, N=self.v1 - self.v0, K=H, x_bs=H, part_bs=self.nparts, norm_w=self.W["norm"],
+                       eps=c["rms_norm_eps"], ban=self.ban, part_val=bb["pv"], part_idx=bb["pi"], idx_offset=self.v0, plan=plan)
+        st = ops.decode_state(bb["nxt"], bb["out"], bb["step"], bb["pos"], advance_pos=True, batch=B)
+        ops.argmax_final(bb["pv"], bb["pi"], self.nparts, st, embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
+        plan.hold(st)
+        return plan
+
+    @torch.no_grad()
+    def generate_batch(self, input_ids_list, max_new_tokens, bad_words_ids=None, eos_token_id=None, min_new_tokens=0):
+        """Greedy generation of several utterances in lockstep (the serving-side batching of inference_vllm.py:109-125, here
+        for up to 4 sequences per step; longer lists run in groups).  Each prompt is prefilled on its own; every decode
+        step then streams the weights once for the whole group.  Per sequence the result equals generate()'s."""
+        if self.tp_path:
+            raise NotImplementedError("batched decode is single-GPU")
+        outs = []
+        for g0 in range(0, len(input_ids_list), 4):
+            outs += self._generate_group(input_ids_list[g0:g0 + 4], max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens)
+        return outs
+
+    def _generate_group(self, ids_list, max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens):
+        B = len(ids_list)
+        for ids in ids_list:
+            if ids.dim() != 2 or ids.shape[0] != 1:
+                raise ValueError("every prompt must be a LongTensor of shape [1, L]")
+        bb = self._batch_buffers(B)
+        self.ban.copy_(self._ban_mask(bad_words_ids))
+        L0 = [int(ids.shape[1]) for ids in ids_list]
+        max_new = min(max_new_tokens, self.ctx_max - max(L0), self.max_out)
+        if max_new <= 0:
+            return [ids.clone() for ids in ids_list]
+        bb["step"].zero_()
+        bb["pos"].copy_(torch.tensor(L0, dtype=torch.int32))
+        for b, ids in enumerate(ids_list):            # per-item prefill into that item's cache / state slot (+ first token)
+            key = (L0[b], b)
+            if key not in bb["prefill"]:
+                bb["prefill"][key] = self._build_prefill(L0[b], None, slot=bb["slots"][b])
+            segs, io = bb["prefill"][key]
+            io["ids"].copy_(ids[0])
+            self._run_segs(segs)
+        if bb["decode"] is None:
+            bb["decode"] = GraphedPlan(self._build_decode_batch(B))
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
+        produced, chunk = 1, 8
+        ends = [None] * B
+        while True:
+            toks = bb["out"][:, :produced].tolist()     # host sync point (EOS check)
+            for b in range(B):
+                if ends[b] is None:
+                    hit = [i for i, t in enumerate(toks[b]) if t in eos and i + 1 >= min_new_tokens]
+                    if hit:
+                        ends[b] = hit[0] + 1
+            if all(e is not None for e in ends) or produced >= max_new:
+                break
+            n = min(chunk, max_new - produced)
+            for _ in range(n):
+                bb["decode"].run()
+            produced += n
+        res = []
+        for b, ids in enumerate(ids_list):
+            n = ends[b] if ends[b] is not None else min(produced, max_new)
+            res.append(torch.cat([ids[0], torch.tensor(toks[b][:n], dtype=torch.long, device=ids.device)]).unsqueeze(0))
+        return res
 
     # ------------------------------------------------------------------ generate
     def _ban_mask(self, bad_words_ids):

@@ -8,7 +8,7 @@ import ctypes as C_
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, AttnArgs, AttnDecodeArgs, DecodeState, GemmArgs, GemvArgs, NormArgs, RopeArgs, SampleArgs, SnakeArgs,
+from ._lib import (BF16, F32, AttnArgs, AttnDecodeArgs, DecodeState, GemmArgs, GemvArgs, GemvBatchArgs, NormArgs, RopeArgs, SampleArgs, SnakeArgs,
                    VbInputArgs, VbSolverArgs, check, lib)
 
 
@@ -222,10 +222,12 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
 
 
-def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True):
+def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True, batch=0):
+    """batch > 1: next_token / step / pos are [batch] and out_tokens is [batch][max_out]."""
     st = DecodeState()
     st.next_token, st.out_tokens, st.step, st.pos = _ptr(next_token), _ptr(out_tokens), _ptr(step), _ptr(pos)
-    st.max_out, st.id_offset, st.advance_pos = out_tokens.numel(), id_offset, int(advance_pos)
+    st.max_out = out_tokens.shape[-1] if batch > 1 else out_tokens.numel()
+    st.id_offset, st.advance_pos, st.batch = id_offset, int(advance_pos), batch
     return st
 
 
@@ -257,12 +259,29 @@ def rope_cache(qkv, cos, sin, kcache, vcache, *, ld, S, pos0, Hq, Hkv, ctx_max, 
     _go(plan, "usdm_rope_cache", lib.usdm_rope_cache, C_.byref(a))
 
 
-def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, plan=None):
+def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
+               residual=None, y16=None, y32=None, ban=None, part_val=None, part_idx=None, idx_offset=0, plan=None):
+    """usdm_gemv_batch: the decode GEMV over nb <= 4 input vectors (x is [nb][x_bs], outputs [nb][y_bs])."""
+    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx)
+    b = GemvBatchArgs()
+    a = b.g
+    a.W, a.ldw, a.N, a.K = _ptr(W), (ldw if ldw is not None else K), N, K
+    a.x, a.norm_w, a.eps = _ptr(x), _ptr(norm_w), eps
+    a.act, a.round_bf16 = act, int(round_bf16)
+    a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
+    a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
+    b.nb, b.x_bs, b.y_bs, b.res_bs, b.part_bs = nb, x_bs, y_bs, res_bs, part_bs
+    _go(plan, "usdm_gemv_batch", lib.usdm_gemv_batch, C_.byref(b))
+
+
+def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,
+                qkv_bs=0, out_bs=0, cache_bs=0, plan=None):
     _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
     a.cos, a.sin, a.kcache, a.vcache = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache)
     a.pm, a.pl, a.po, a.out, a.counters = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out), _ptr(counters)
+    a.batch, a.qkv_bs, a.out_bs, a.cache_bs = batch, qkv_bs, out_bs, cache_bs
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
