@@ -17,6 +17,8 @@ __device__ __forceinline__ float dot8b(u32x4 w, u32x4 x, float acc) {
   return acc;
 }
 
+// (NB = 4 needs 140 VGPRs in the gate/up variant = 3 workgroups per SIMD instead of 4, i.e. a third round of workgroups for
+// the 1792-workgroup launch: 57 us instead of 40.  Forcing 128 VGPRs spills and was measured slower: 898 vs 967 tok/s.)
 template <int RW, bool GLU, int NWV, int NB>
 __global__ __launch_bounds__(NWV * 64) void gemv_batch_kernel(const usdm_gemv_batch_args ba) {
   const usdm_gemv_args& a = ba.g;
