@@ -15,6 +15,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 FLAGS += os.environ.get("USDM_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DUSDM_GEMM_TRACE for tools/gemm_trace.py
 
 
+# per-file extra flags.  attn.hip: MFMA results stay in VGPRs (the softmax consumes them with VALU ops; with the default AGPR
+# form 22 % of the loop's VALU instructions were v_accvgpr_read/write moves)
+EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -37,7 +42,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(bdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, src):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

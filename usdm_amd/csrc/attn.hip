@@ -28,17 +28,23 @@ __device__ unsigned long long g_attn_trace[4096 * 8];
 #define ATR_ADD(i, t0) do { } while (0)
 #endif
 
-template <int DH, int MODE, int NW>  // MODE 0: bidirectional + ALiBi + key-length mask ; 1: causal ; NW waves x 32 queries
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
-  constexpr int NT = NW * 64;   // threads
+// MODE 0: bidirectional + ALiBi + key-length mask ; 1: causal ; NW waves x 32 queries ; KS key-split groups: group g of NW
+// waves walks key tiles g, g+KS, ... of the SAME queries and the groups' (m, l, O) are merged at the end.  KS = 2 puts two
+// waves on every SIMD when the grid is about one workgroup per CU (Voicebox: 288 workgroups): one wave's softmax VALU work
+// then overlaps the other's LDS-fed MFMAs (per-phase cycle counts in profiles/r01_gemm_ablation.txt).
+template <int DH, int MODE, int NW, int KS = 1>
+__global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args a) {
+  constexpr int NT = NW * 64;   // threads of one key-split group (the loaders below are per group)
   constexpr int QB = NW * 32;   // queries per workgroup
   constexpr int DS = DH / 16;  // d-steps of QK^T
   constexpr int DT = DH / 32;  // 32-row tiles of O^T
   constexpr int KROW = DH * 2; // bytes per K row
   constexpr int STAGE = KT * KROW + DH * KT * 2;  // K tile + V^T tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem_all[2 * STAGE * KS];
+  const int grp = threadIdx.x / NT;                 // key-split group of this wave
+  char* smem = smem_all + grp * 2 * STAGE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (a.Hq / a.Hkv);
@@ -123,12 +129,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
   unsigned long long atr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tph = ATR_T();
   const unsigned long long tstart = tph;
-  if (ntiles > 0) { load_tile(0); store_tile(0); }
-  if (ntiles > 1) load_tile(1);
+  // group-local tile sequence: it-th tile of this group is key tile grp + KS * it
+  const int nit = (ntiles + KS - 1) / KS;                  // barrier count is the same for every group
+  const int myn = ntiles > grp ? (ntiles - grp + KS - 1) / KS : 0;
+  if (myn > 0) { load_tile(grp); store_tile(0); }
+  if (myn > 1) load_tile(grp + KS);
   __syncthreads();
   ATR_ADD(0, tph);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* sK = smem + (kt & 1) * STAGE;
+  for (int it = 0; it < nit; ++it) {
+    if (it >= myn) { __syncthreads(); continue; }          // this group has run out of tiles (wave-uniform)
+    const int kt = grp + KS * it;
+    const char* sK = smem + (it & 1) * STAGE;
     const char* sV = sK + KT * KROW;
 
     // ---- S^T = K . Q^T for the two 32-key sub-tiles
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
         }
       }
     ATR_ADD(3, tph);
-    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
-    if (kt + 2 < ntiles) load_tile(kt + 2);
+    if (it + 1 < myn) store_tile((it + 1) & 1);
+    if (it + 2 < myn) load_tile(kt + 2 * KS);
     ATR_ADD(4, tph);
     __syncthreads();
     ATR_ADD(5, tph);
@@ -239,6 +250,30 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const usdm_attn_args a) {
   }
 #endif
 
+  if constexpr (KS > 1) {
+    // ---- merge the key-split groups: groups 1.. park (m, l, O^T) in LDS, group 0 folds them in (same wave / lane)
+    static_assert(KS == 2, "merge is written for two groups");
+    static_assert(NW * 64 * (2 + DT * 16) * 4 <= 2 * STAGE * KS, "merge buffer");
+    float* mb = (float*)smem_all + (wave * 64 + lane) * (2 + DT * 16);
+    __syncthreads();                                       // every tile buffer is dead
+    if (grp == 1) {
+      mb[0] = m_run; mb[1] = l_run;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mb[2 + t * 16 + r] = oacc[t][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = mb[0], l1 = mb[1];
+    const float mm = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] = oacc[t][r] * a0 + mb[2 + t * 16 + r] * a1;
+  }
   // ---- normalise and store O[q][h*DH + d] (bf16)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -278,6 +313,14 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   const bool small = getenv("USDM_ATTN_NW2") && (int64_t)cdiv(a.Sq, 128) * a.Hq * a.B < 1024;
   const int qb = small ? 64 : 128;
   dim3 grid(cdiv(a.Sq, qb), a.Hq, a.B), block(small ? 128 : 256);
+  // key-split pairs of waves when the grid leaves about one 4-wave workgroup per CU and there are enough key tiles
+  static const int ks_env = getenv("USDM_ATTN_KS") ? atoi(getenv("USDM_ATTN_KS")) : -1;
+  const bool ks2 = !small && a.dh == 64 && a.mode == 0 && (ks_env == 2);   // measured: no gain in situ (NFE 5.65 vs 5.58 ms), kept as an experiment switch
+  if (ks2) {
+    hipLaunchKernelGGL((attn_kernel<64, 0, 4, 2>), grid, dim3(512), 0, st, a);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
 #define USDM_ATTN(DHV, MODEV)                                                                 \
   do {                                                                                         \
     if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a);        \
