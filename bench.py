@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--text-tokens", type=int, default=32)
     ap.add_argument("--nt", type=int, default=64, help="Voicebox n_timesteps (Heun halves it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the informational batched-decode measurement")
     ap.add_argument("--vocoder-dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the multi-rank code path (process group, collectives, TP plan segments) on however many ranks there are")
@@ -226,6 +227,20 @@ def cpu_baseline(args):
                       "layer at 499 frames (x35) + k-means"}
 
 
+def batched_decode_rate(llm, B=4, new_tokens=96):
+    """Informational (outside the timed region): aggregate decode tokens/s of generate_batch — B utterances in lockstep, weights
+    streamed once per step.  Not part of `value`."""
+    dev = llm.device
+    gen = torch.Generator().manual_seed(11)
+    prompts = [torch.randint(32002, 42002, (1, 560 - 8 * b), generator=gen).to(dev) for b in range(B)]
+    llm.generate_batch(prompts, max_new_tokens=24)      # plans + graph capture
+    torch.cuda.synchronize()
+    t = time.perf_counter(); llm.generate_batch(prompts, max_new_tokens=8); torch.cuda.synchronize(); t1 = time.perf_counter() - t
+    t = time.perf_counter(); llm.generate_batch(prompts, max_new_tokens=8 + new_tokens); torch.cuda.synchronize(); t2 = time.perf_counter() - t
+    return {"batch": B, "tokens_per_s": round(B * new_tokens / (t2 - t1), 1), "ms_per_step": round(1e3 * (t2 - t1) / new_tokens, 3),
+            "note": "aggregate over the batch; decode steps only"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -313,6 +328,8 @@ def main():
     }
     if rank == 0:
         res["roofline"] = measure_gemv_roofline(pipe.llm)
+        if world == 1 and not args.no_batched:
+            res["llm_batched_decode"] = batched_decode_rate(pipe.llm)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
     elif dist_on:
