@@ -149,3 +149,52 @@ def test_swiglu_and_qkv(dev):
     _check(q[:, :, :S].float(), ref[:, :, 0].permute(0, 2, 1, 3), torch.bfloat16, K, "q")
     _check(k[:, :, :S].float(), ref[:, :, 1].permute(0, 2, 1, 3), torch.bfloat16, K, "k")
     _check(v[:, :, :, :S].float(), ref[:, :, 2].permute(0, 2, 3, 1), torch.bfloat16, K, "v^T")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N", [(300, 200), (129, 50), (257, 130)])
+def test_epilogue_variants(dev, dtype, M, N):
+    """Every store path of the epilogue: activation + residual (rolled loop), ragged N with activation (scalar path),
+    transposed output with bias + activation + residual (transposed LDS tile), bf16 residual, alpha."""
+    from usdm_amd import ops
+    K = 64
+    A, W = _rand((M, K), dtype, 1, 0.3), _rand((N, K), dtype, 2, 0.3)
+    b = _rand((N,), torch.float32, 3)
+    R = _rand((M, N), torch.float32, 4)
+    pre = 0.5 * (A.double() @ W.double().T) + b.double()
+    # row-major, GELU then residual
+    out = torch.zeros((M, N), device=dev)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), alpha=0.5, act=1, residual=R.to(dev), ldr=N, out32=out)
+    _check(out, torch.nn.functional.gelu(pre) + R.double(), dtype, K, "gelu+residual")
+    # tanh, bf16 output, no residual
+    out16 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), alpha=0.5, act=4, out16=out16)
+    _check(out16.float(), torch.tanh(pre), torch.bfloat16, K, "tanh bf16")
+    # transposed output [N][M] with bias, GELU and a residual laid out like the output's logical [M][N]
+    outT = torch.zeros((N, M), device=dev)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), alpha=0.5, act=1, residual=R.to(dev), ldr=N, out32=outT, ldc=M,
+             transpose_out=True)
+    _check(outT, (torch.nn.functional.gelu(pre) + R.double()).T, dtype, K, "transpose+gelu+residual")
+    # bf16 residual, plain
+    Rb = R.to(torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), alpha=0.5, residual=Rb.to(dev), ldr=N, out32=out)
+    _check(out, pre + Rb.double(), dtype, K, "bf16 residual")
+
+
+def test_qkv_epilogue_full_shape(dev):
+    """Head-split QKV epilogue at the Voicebox layer shape (several tiles per part, bias, V^T through the transposed tile)."""
+    from usdm_amd import ops
+    B, S, Hh, D, K = 2, 1118, 16, 64, 128
+    Spad = (S + 63) // 64 * 64
+    A = _rand((B * S, K), torch.bfloat16, 21)
+    W = _rand((3 * Hh * D, K), torch.bfloat16, 22, 0.2)
+    b = _rand((3 * Hh * D,), torch.float32, 23)
+    q = torch.zeros((B, Hh, Spad, D), device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    v = torch.zeros((B, Hh, D, Spad), device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), M=B * S, N=3 * Hh * D, Kc=K, bias=b.to(dev), qkv=dict(S=S, Spad=Spad, H=Hh, D=D, q=q, k=k, v=v))
+    ref = (A.double() @ W.double().T + b.double()).reshape(B, S, 3, Hh, D)
+    _check(q[:, :, :S].float(), ref[:, :, 0].permute(0, 2, 1, 3), torch.bfloat16, K, "q")
+    _check(k[:, :, :S].float(), ref[:, :, 1].permute(0, 2, 1, 3), torch.bfloat16, K, "k")
+    _check(v[:, :, :, :S].float(), ref[:, :, 2].permute(0, 2, 3, 1), torch.bfloat16, K, "v^T")
+    assert float(v[:, :, :, S:].abs().max()) == 0.0 and float(q[:, :, S:].abs().max()) == 0.0   # padding untouched
