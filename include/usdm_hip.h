@@ -79,6 +79,10 @@ typedef struct usdm_gemm_args {
   /* USDM_EPI_QKV_HEADS: N = 3*H*D, rows m = b*S + s; Q,K -> [B][H][S_pad][D], V -> [B][H][D][S_pad] */
   int32_t qkv_S, qkv_Spad, qkv_H, qkv_D;
   void *qkv_q, *qkv_k, *qkv_v; /* bf16 */
+  /* split-K (single-tap, plain f32 output only): grid z is multiplied by split_k; split s accumulates its share of the K
+   * chunks and stores to C32 + s*c_split_stride; bias and residual are applied by split 0 only.  The consumer sums the
+   * partials (e.g. usdm_norm's `res` input).  For deep-K problems whose output tiles do not fill the chip. */
+  int32_t split_k; int64_t c_split_stride;
 } usdm_gemm_args;
 
 int usdm_gemm(const usdm_gemm_args* args, usdm_stream_t stream);

@@ -198,3 +198,18 @@ def test_qkv_epilogue_full_shape(dev):
     _check(k[:, :, :S].float(), ref[:, :, 1].permute(0, 2, 1, 3), torch.bfloat16, K, "k")
     _check(v[:, :, :, :S].float(), ref[:, :, 2].permute(0, 2, 3, 1), torch.bfloat16, K, "v^T")
     assert float(v[:, :, :, S:].abs().max()) == 0.0 and float(q[:, :, S:].abs().max()) == 0.0   # padding untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,S", [(300, 200, 512, 2), (2236, 1024, 4096, 2), (129, 130, 448, 3), (499, 1280, 5120, 4)])
+def test_split_k(dev, dtype, M, N, K, S):
+    """split-K partial outputs: their sum equals the unsplit GEMM; bias and residual are applied exactly once."""
+    from usdm_amd import ops
+    A, W = _rand((M, K), dtype, 1, 0.3), _rand((N, K), dtype, 2, 0.3)
+    b = _rand((N,), torch.float32, 3)
+    R = _rand((M, N), torch.float32, 4)
+    parts = torch.full((S, M, N), float("nan"), device=dev)
+    ops.gemm(A.to(dev), W.to(dev), M=M, N=N, Kc=K, bias=b.to(dev), residual=R.to(dev), ldr=N, out32=parts, split_k=S,
+             c_split_stride=M * N)
+    ref = A.double() @ W.double().T + b.double() + R.double()
+    _check(parts.sum(0), ref, dtype, K, f"split_k={S}")

@@ -19,14 +19,18 @@ h32, tmp32 = rnd(R, H), torch.zeros(R, H, device=dev)
 q = torch.zeros(Bx, nh, Spad, 64, device=dev, dtype=bf); k = torch.zeros_like(q); vt = torch.zeros(Bx, nh, 64, Spad, device=dev, dtype=bf)
 o16 = torch.zeros(R, I, device=dev, dtype=bf)
 b3, b1, bI = rnd(3 * H), rnd(H), rnd(I)
+tmp32s = torch.zeros(4, R, H, device=dev)
 kinds = {
     "qkv  (N3072 K1024, head-split epilogue)": lambda W, p: ops.gemm(x16, W, M=R, N=3 * H, Kc=H, bias=b3, plan=p, qkv=dict(S=S, Spad=Spad, H=nh, D=64, q=q, k=k, v=vt)),
     "qkv* (same, plain bf16 epilogue)       ": lambda W, p: ops.gemm(x16, W, M=R, N=3 * H, Kc=H, bias=b3, out16=o16, ldc=I, plan=p),
     "wo   (N1024 K1024, +res f32 out)       ": lambda W, p: ops.gemm(x16, W, M=R, N=H, Kc=H, bias=b1, residual=h32, ldr=H, out32=tmp32, plan=p),
     "w1   (N4096 K1024, GELU bf16 out)      ": lambda W, p: ops.gemm(x16, W, M=R, N=I, Kc=H, bias=bI, act=1, out16=o16, plan=p),
     "w2   (N1024 K4096, +res f32 out)       ": lambda W, p: ops.gemm(f16, W, M=R, N=H, Kc=I, bias=b1, residual=h32, ldr=H, out32=tmp32, plan=p),
+    "w2*  (same, split-K 2)                 ": lambda W, p: ops.gemm(f16, W, M=R, N=H, Kc=I, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=2, c_split_stride=R * H, plan=p),
+    "w2*  (same, split-K 4)                 ": lambda W, p: ops.gemm(f16, W, M=R, N=H, Kc=I, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=4, c_split_stride=R * H, plan=p),
+    "wo*  (N1024 K1024, split-K 2)          ": lambda W, p: ops.gemm(x16, W, M=R, N=H, Kc=H, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=2, c_split_stride=R * H, plan=p),
 }
-wkey = ["qkv", "qkv", "wo", "w1", "w2"]
+wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo"]
 tot = 0.0
 for (name, f), wk in zip(kinds.items(), wkey):
     plan = ops.Plan()

@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("c_row_mul", C.c_int32), ("c_row_off", C.c_int32), ("transpose_out", C.c_int32), ("epi", C.c_int32),
         ("qkv_S", C.c_int32), ("qkv_Spad", C.c_int32), ("qkv_H", C.c_int32), ("qkv_D", C.c_int32),
         ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_v", C.c_void_p),
+        ("split_k", C.c_int32), ("c_split_stride", C.c_int64),
     ]
 
 

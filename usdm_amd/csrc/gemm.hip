@@ -94,7 +94,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z;
+  const int nsplit = a.split_k > 1 ? a.split_k : 1;
+  const int ksi = blockIdx.z % nsplit;          // split-K share of this workgroup
+  const int z = blockIdx.z / nsplit;
   const int bz = z / a.groups, gz = z - bz * a.groups;
 
   const char* Abase = (const char*)a.A + (a.a_gstride * gz + a.a_bstride * bz) * ES;
@@ -104,7 +106,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
 
   const int cpt = a.Kc / CE;            // chunks per tap
   const int Q = a.taps * cpt;           // total chunks
-  const int nks = (Q + NCH - 1) / NCH;       // K-steps (NCH chunks each)
+  int q_lo = 0, q_hi = Q;                    // chunk range of this split (whole K when split_k <= 1)
+  if (nsplit > 1) {
+    const int per = ((Q + nsplit - 1) / nsplit + NCH - 1) / NCH * NCH;
+    q_lo = ksi * per; q_hi = q_lo + per < Q ? q_lo + per : Q;
+    if (q_lo > q_hi) q_lo = q_hi;
+  }
+  const int nks = (q_hi - q_lo + NCH - 1) / NCH;       // K-steps (NCH chunks each)
 
   // loader coordinates of this thread
   const int sub = (tid >> 2) & 1, pc = tid & 3, r0 = tid >> 3;
@@ -114,8 +122,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   u32x4 ra0[LA], rb0[LB], ra1[LA], rb1[LB];  // two register stages: loads run two K-steps ahead of the MFMAs
 
   auto load_regs = [&](int ks, u32x4* ra, u32x4* rb) {
-    const int q = 2 * ks + sub;
-    const bool qv = q < Q;
+    const int q = q_lo + 2 * ks + sub;
+    const bool qv = q < q_hi;
     const int tap = q / cpt;
     const int cb = (q - tap * cpt) * CE + pc * PE;
     const unsigned colA = (unsigned)((cb + (int64_t)tap * a.a_tap_stride) * ES);
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
 
   // epilogue ownership: thread -> 4 fixed output columns; their bias is fetched here, under the K loop
   const int gcol = a.c_gcol * gz;
-  const float* bias = a.bias;
+  const float* bias = ksi == 0 ? a.bias : nullptr;   // bias and residual belong to split 0
   const bool swiglu = a.act == USDM_ACT_SWIGLU;
   constexpr int C4 = BN / 4, RPI = NTH / C4, NIT = BM / RPI;
   const int ec = (tid % C4) * 4, er = tid / C4;
@@ -221,23 +229,23 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   auto dma_issue = [&](int stage, int ks, int i0, int i1, int j0, int j1) {
     char* sAst = smem + stage * STAGE;
     char* sBst = sAst + BM * 64 * NCH;
-    const unsigned kcol = (unsigned)(NCH * ks * 64);     // NCH chunks of 64 B per K-step
+    const unsigned kcol = (unsigned)((q_lo + NCH * ks) * 64);     // NCH chunks of 64 B per K-step
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       if (i < i0 || i >= i1) continue;
       const int qi = wv + NWV * i;
       if (QA % NWV != 0 && qi >= QA) break;
       const int sb = qi / (BM / 16);
-      const int q = NCH * ks + sb;
+      const int q = q_lo + NCH * ks + sb;
       unsigned off;
       if (simple) {
-        off = (q < Q) ? dofA[i] + kcol : OOB;
+        off = (q < q_hi) ? dofA[i] + kcol : OOB;
       } else {
         const int lp = lane & 3, r = drA[i];
         const int tap = q / cpt;
         const int cb = (q - tap * cpt) * CE + (lp ^ swz(r)) * PE;
         const int row = (m0 + r) * a.a_row_mul + a.a_row_off + tap * a.a_row_step;
-        const bool v = (q < Q) && ((unsigned)row < (unsigned)a.rowsA);
+        const bool v = (q < q_hi) && ((unsigned)row < (unsigned)a.rowsA);
         off = v ? ((unsigned)row * lda_b + (unsigned)((cb + (int64_t)tap * a.a_tap_stride) * ES)) : OOB;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAst + qi * 1024), 16, off, 0, 0, 0);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       const int qi = wv + NWV * i;
       if (QB % NWV != 0 && qi >= QB) break;
       const int sb = qi / (BN / 16);
-      const unsigned off = (NCH * ks + sb < Q) ? dofB[i] + kcol : OOB;
+      const unsigned off = (q_lo + NCH * ks + sb < q_hi) ? dofB[i] + kcol : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBst + qi * 1024), 16, off, 0, 0, 0);
     }
   };
@@ -359,6 +367,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // inside the store loop costs a full memory latency per iteration (measured: 14 us of a 33 us 128x128 tile).
   TR(3);
   float* ct = (float*)smem;  // [BM][CST] f32, or [BN][CSTT] in transposed mode
+  const void* resid = ksi == 0 ? a.residual : nullptr;                                     // split-K: split 0 owns bias + residual
+  float* C32p = a.C32 ? (float*)a.C32 + (int64_t)ksi * a.c_split_stride : nullptr;
   const bool rbf = a.round_bf16 != 0;
   const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
 
@@ -440,13 +450,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         for (int e = 0; e < mv; ++e) {
           const int64_t rw = row + (int64_t)e * a.c_row_mul;
           float x = v[e];
-          if (a.residual) {
+          if (resid) {
             const int64_t ri = rw * a.ldr + gcol + n;
-            x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+            x += (a.res_dtype == USDM_F32) ? ((const float*)resid)[ri] : bf2f(((const bf16_t*)resid)[ri]);
             if (rbf) x = round_bf(x);
           }
           const int64_t oi = (int64_t)(gcol + n) * a.ldc + rw;
-          if (a.C32) ((float*)a.C32)[oi] = x;
+          if (C32p) C32p[oi] = x;
           if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
         }
       }
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         for (int e = 0; e < 4; ++e) o[e] = silu_mul(a.alpha * gt[e] + bv[e], a.alpha * up[e] + bu[e], rbf);
         const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
         const int64_t oi = row * a.ldc + (gcol >> 1) + nout;
-        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if (C32p) *(float4*)(C32p + oi) = make_float4(o[0], o[1], o[2], o[3]);
         if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
       }
     }
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // ---- row-major outputs (and Q / K tiles of the head-split epilogue): thread = 4 fixed columns, rows er, er + RPI, ...
   const int n = n0 + ec;
   const int nv = (a.N - n) < 4 ? (a.N - n) : 4;   // <= 0: this thread's columns are outside the matrix
-  const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!a.residual || (a.ldr & 3) == 0));
+  const bool vec_ok = is_qkv ? true : (((a.ldc | gcol) & 3) == 0 && (!resid || (a.ldr & 3) == 0));
   auto act_fn = [&](float x) -> float {
     if (a.act == USDM_ACT_GELU) return gelu_erf(x);
     if (a.act == USDM_ACT_TANH) return tanhf(x);
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   } else if (nv == 4 && vec_ok && a.act != USDM_ACT_NONE) {
     // activation epilogues: ROLLED loop so the transcendental code exists once (an unrolled epilogue grew the kernel to
     // 88 KB and ran out of the instruction cache); the next row's LDS read is issued under this row's math
-    const bool has_res = a.residual != nullptr;
+    const bool has_res = resid != nullptr;
     const int64_t rstep = (int64_t)RPI * a.c_row_mul;
     int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
     float4 cv = *(const float4*)(ct + er * CST + ec);
@@ -551,10 +561,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       if (has_res) {
         const int64_t ri = row * a.ldr + gcol + n;
         if (a.res_dtype == USDM_F32) {
-          const float4 rv = *(const float4*)((const float*)a.residual + ri);
+          const float4 rv = *(const float4*)((const float*)resid + ri);
           v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
         } else {
-          const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+          const uint2 rv = *(const uint2*)((const bf16_t*)resid + ri);
           v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
         }
         if (rbf) {
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         }
       }
       const int64_t oi = row * a.ldc + gcol + n;
-      if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+      if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
       if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
     }
   } else if (nv == 4 && vec_ok) {
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     // the store loop costs a full memory latency per iteration: measured 14 us of a 33 us 128x128 tile)
     constexpr int NB = NIT < 8 ? NIT : 8;
     static_assert(NIT % NB == 0, "epilogue batches");
-    const bool has_res = a.residual != nullptr;
+    const bool has_res = resid != nullptr;
     const int64_t rstep = (int64_t)RPI * a.c_row_mul;
     int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
 #pragma unroll 1
@@ -585,9 +595,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           if (m < a.M) {
             const int64_t ri = (row + u * rstep) * a.ldr + gcol + n;
             if (a.res_dtype == USDM_F32) {
-              rres[u] = *(const float4*)((const float*)a.residual + ri);
+              rres[u] = *(const float4*)((const float*)resid + ri);
             } else {
-              const uint2 rv = *(const uint2*)((const bf16_t*)a.residual + ri);
+              const uint2 rv = *(const uint2*)((const bf16_t*)resid + ri);
               rres[u] = make_float4(bf2f(rv.x & 0xffff), bf2f(rv.x >> 16), bf2f(rv.y & 0xffff), bf2f(rv.y >> 16));
             }
           }
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           }
         }
         const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
-        if (a.C32) *(float4*)((float*)a.C32 + oi) = make_float4(v[0], v[1], v[2], v[3]);
+        if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
         if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
       }
       row += NB * rstep;
@@ -628,13 +638,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         float x = a.alpha * ct[r * CST + ec + e] + bv[e];
         if (rbf) x = round_bf(x);
         x = act_fn(x);
-        if (a.residual) {
+        if (resid) {
           const int64_t ri = row * a.ldr + gcol + n + e;
-          x += (a.res_dtype == USDM_F32) ? ((const float*)a.residual)[ri] : bf2f(((const bf16_t*)a.residual)[ri]);
+          x += (a.res_dtype == USDM_F32) ? ((const float*)resid)[ri] : bf2f(((const bf16_t*)resid)[ri]);
           if (rbf) x = round_bf(x);
         }
         const int64_t oi = row * a.ldc + gcol + n + e;
-        if (a.C32) ((float*)a.C32)[oi] = x;
+        if (C32p) C32p[oi] = x;
         if (a.C16) ((bf16_t*)a.C16)[oi] = f2bf(x);
       }
     }
@@ -652,7 +662,7 @@ int launch(const usdm_gemm_args& a, hipStream_t st) {
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
-  dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch);
+  dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1));
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
@@ -691,6 +701,9 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t wmax = ((int64_t)a.N * a.ldw) * es;
   USDM_CHECK_ARG(amax < 0x7FFFFF00ll && wmax < 0x7FFFFF00ll, "usdm_gemm: operand exceeds 2 GiB addressing window");
   USDM_CHECK_ARG(a.C32 || a.C16 || a.epi == USDM_EPI_QKV_HEADS, "usdm_gemm: no output");
+  USDM_CHECK_ARG(a.split_k <= 1 || (a.split_k <= 16 && a.taps == 1 && a.C32 && !a.C16 && a.act == USDM_ACT_NONE && !a.round_bf16 &&
+                                    !a.transpose_out && a.epi == USDM_EPI_PLAIN && a.c_split_stride > 0),
+                 "usdm_gemm: split_k needs a single-tap GEMM with a plain f32 output (no activation / bf16 rounding / transpose)");
   if (a.act == USDM_ACT_SWIGLU)
     USDM_CHECK_ARG(a.N % 32 == 0 && !a.transpose_out && !a.residual && a.ldc % 4 == 0 && a.c_gcol % 8 == 0 && a.epi == USDM_EPI_PLAIN,
                    "usdm_gemm: swiglu needs N%%32==0, ldc%%4==0, row-major output, no residual");
@@ -700,7 +713,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
                    "usdm_gemm: bad qkv epilogue args");
   hipStream_t st = (hipStream_t)stream;
   // tile selection, measured on MI355X (profiles/r01_gemm_tiles.txt, profiles/r01_gemm_ablation.txt)
-  const int64_t z = (int64_t)a.groups * a.batch;
+  const int64_t z = (int64_t)a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1);
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
   int sel;  // 0-2: register-staged 128x128 / 128x64 / 64x64; 4-6: the same tiles with 2-stage LDS-DMA; 7-11: deeper DMA pipelines
@@ -709,7 +722,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 1;
   if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
   else if (heur == 1 && a.taps == 1) {
-    if (t128 >= 640) sel = 4;                                          // many rounds of the big tile
+    if (a.split_k > 1 && t128 >= 224 && t128 <= 512) sel = 4;          // split-K partials filling one round of the big tile
+    else if (t128 >= 640) sel = 4;                                     // many rounds of the big tile
     else if (a.Kc >= 8192 && t128 >= 128 && t128 <= 256) sel = 11;     // one deep-K tile per CU: 3-stage DMA pipeline
     else if (a.Kc >= 2048 && t12864 >= 256) sel = 10;                  // deep K, few tiles: 128x64, 3 stages
     else if (t128 >= 400 && t128 <= 512) sel = 4;                      // exactly one round of 2 workgroups per CU
