@@ -185,3 +185,45 @@ def test_tp_code_path_single_rank_nccl(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tp_seg", [False, True])
+def test_prefix_kv_reuse(dev, tp_seg):
+    """Three chained rounds as in src/inference.py:61-83 (each prompt = previous output + a few tokens).  Prefilling only the
+    new tokens on top of the cached K/V must reproduce a from-scratch prefill up to bf16 rounding of the cached rows (rows
+    appended by decode steps come from the GEMV path): next-token logits within 3e-2 of the logit range, and the same token
+    whenever the from-scratch top-2 gap exceeds that."""
+    import os
+    import torch.distributed as dist
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    kw = {}
+    if tp_seg:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        kw = dict(tp_segments=True, group=dist.group.WORLD)
+    sd = MO.random_state_dict(SMALL, seed=21)
+    a = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw)
+    b = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw)
+    a.reuse_prefix, a.keep_logits, b.keep_logits = True, True, True
+    g = torch.Generator().manual_seed(5)
+    p = torch.randint(0, 1000, (1, 70), generator=g).to(dev)
+    for rnd, (new, extra) in enumerate([(13, 5), (9, 1), (20, 3)]):
+        # first-token logits of this round: reuse (a) vs from scratch (b)
+        a.generate(input_ids=p, max_new_tokens=1); la = a.last_logits.clone()
+        b.generate(input_ids=p, max_new_tokens=1); lb = b.last_logits.clone()
+        rng = float(lb.max() - lb.min())
+        assert float((la - lb).abs().max()) <= 3e-2 * rng, (rnd, float((la - lb).abs().max()), rng)
+        top2 = lb.topk(2).values
+        if float(top2[0] - top2[1]) > 3e-2 * rng:
+            assert int(la.argmax()) == int(lb.argmax())
+        if rnd:
+            assert any(k[1] > 0 for k in a._prefill_plans), "the round did not reuse the cached prefix"
+        oa = a.generate(input_ids=p, max_new_tokens=new)      # (this call reuses the whole prompt but its last token)
+        assert oa.shape[1] == p.shape[1] + new
+        p = torch.cat([oa, torch.randint(0, 1000, (1, extra), generator=g).to(dev)], 1)
+    # round 0 had nothing cached: bit-identical to the from-scratch model
+    a2 = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw); a2.reuse_prefix = True
+    q = torch.randint(0, 1000, (1, 50), generator=g).to(dev)
+    assert torch.equal(a2.generate(input_ids=q, max_new_tokens=8), b.generate(input_ids=q, max_new_tokens=8))

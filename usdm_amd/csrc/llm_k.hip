@@ -10,6 +10,9 @@
 #include <stdlib.h>
 #include "../../include/usdm_hip.h"
 
+#ifndef USDM_UNR1
+#define USDM_UNR1 8   // ring depth of the one-row-per-wave variants (o_proj / down_proj)
+#endif
 namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
@@ -42,7 +45,7 @@ template <int RW, bool GLU, int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
   constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
-  constexpr int UNR = (NR >= 8) ? 2 : (NR >= 4) ? 4 : (NR == 3 ? 5 : 8);  // ring depth: NR*UNR = 15..16 loads in flight per lane
+  constexpr int UNR = (NR >= 8) ? 2 : (NR >= 4) ? 4 : (NR == 3 ? 5 : (NR == 2 ? 8 : USDM_UNR1));  // ring depth: NR*UNR = 15..16 loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;  // [Kpad] bf16, zero padded
   __shared__ float red[NWV];

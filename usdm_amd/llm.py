@@ -151,6 +151,15 @@ class USDMForCausalLM:
         bf = torch.bfloat16
         self.kcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
         self.vcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
+        # V^T of the prompt tokens (what the prefill attention consumes), kept across generate() calls so that a prompt which
+        # extends the cached sequence only prefills its new tokens (the reference's three rounds: src/inference.py:61-83)
+        import os
+        # Opt-in (USDM_PREFIX_REUSE=1 or .reuse_prefix = True): cached rows written by decode steps come from the GEMV path and
+        # can differ from a from-scratch prefill by a bf16 ulp, so the result is close to, not bit-identical with, the
+        # reference's recompute-every-round behaviour.
+        self.reuse_prefix = os.environ.get("USDM_PREFIX_REUSE", "0") == "1"
+        self.vtc = torch.zeros(L, self.Hkv, d, self.ctx_max, dtype=bf, device=dev)
+        self._kv_ids, self._vt_upto = None, 0
         # rope tables exactly as HF MistralRotaryEmbedding computes them (fp32 on the host, cast to bf16)
         inv_freq = 1.0 / (c["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
         fr = torch.arange(self.ctx_max).float()[:, None] * inv_freq[None, :]
@@ -211,7 +220,9 @@ class USDMForCausalLM:
         segs.append(plan)
 
     # ------------------------------------------------------------------ plans
-    def _build_prefill(self, S, sampling=None, slot=None):
+    def _build_prefill(self, S, sampling=None, slot=None, past=0):
+        """Prefill of S new tokens at positions past .. past+S-1 (past > 0: the KV cache already holds the first `past`
+        tokens of the same sequence; only the single-sequence cache keeps the V^T that makes this possible)."""
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
@@ -221,18 +232,26 @@ class USDMForCausalLM:
         Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
         io = dict(ids=Z(S, dt=torch.int64))
         h, xn, qkv, ao, act = Z(S, H), Z(S, H), Z(S, nq), Z(S, Hq * d), Z(S, I)
-        vt = Z(Hkv, d, Spad)
+        vt = Z(Hkv, d, Spad) if slot is not None else None     # batch slots: scratch V^T of this prompt only
+        assert past == 0 or slot is None
         part = Z(S, H, dt=torch.float32) if tp > 1 else None
         ops.embed_rows(self.W["embed"], h, Hd=H, ids=io["ids"], n=S, plan=plan)
         for l in range(L):
             w = self.W["layers"][l]
             ops.norm(h, w["ln1"], None, rows=S, C=H, eps=c["rms_norm_eps"], rms=True, round_bf16=True, out16=xn, plan=plan)
             ops.gemm(xn, w["qkv"], M=S, N=nq, Kc=H, out16=qkv, plan=plan)
-            ops.rope_cache(qkv, self.cos, self.sin, (slot or self).kcache[l], (slot or self).vcache[l], ld=nq, S=S, pos0=0, Hq=Hq, Hkv=Hkv,
-                           ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=vt, vt_ld=Spad, plan=plan)
-            ops.attention(qkv, (slot or self).kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
-                          q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d), v_strides=(0, d * Spad, Spad),
-                          o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
+            if slot is not None:
+                ops.rope_cache(qkv, self.cos, self.sin, slot.kcache[l], slot.vcache[l], ld=nq, S=S, pos0=0, Hq=Hq, Hkv=Hkv,
+                               ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=vt, vt_ld=Spad, plan=plan)
+                ops.attention(qkv, slot.kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
+                              q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d), v_strides=(0, d * Spad, Spad),
+                              o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
+            else:
+                ops.rope_cache(qkv, self.cos, self.sin, self.kcache[l], self.vcache[l], ld=nq, S=S, pos0=past, Hq=Hq, Hkv=Hkv,
+                               ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=self.vtc[l][:, :, past:], vt_ld=self.ctx_max, plan=plan)
+                ops.attention(qkv, self.kcache[l], self.vtc[l], ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=past + S,
+                              Skv_alloc=self.ctx_max, q_pos0=past, q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d),
+                              v_strides=(0, d * self.ctx_max, self.ctx_max), o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
             if tp == 1:
                 ops.gemm(ao, w["o"], M=S, N=H, Kc=Hq * d, residual=h, ldr=H, round_bf16=True, out16=h, plan=plan)
             else:
@@ -481,10 +500,27 @@ class USDMForCausalLM:
         max_new_tokens = min(max_new_tokens, self.ctx_max - L0, self.max_out)
         if max_new_tokens <= 0:
             return input_ids.clone()
-        if (L0, sampling) not in self._prefill_plans:
-            self._prefill_plans[(L0, sampling)] = self._build_prefill(L0, sampling)
-        segs, io = self._prefill_plans[(L0, sampling)]
-        io["ids"].copy_(input_ids[0])
+        # prefix reuse: tokens whose K/V are already cached (same ids at the same positions) are not prefilled again
+        past, ids_host = 0, None
+        if self.reuse_prefix:
+            ids_host = input_ids[0].tolist()
+            if self._kv_ids is not None:
+                n = min(len(ids_host) - 1, len(self._kv_ids))
+                while past < n and ids_host[past] == self._kv_ids[past]:
+                    past += 1
+                if past < 16:
+                    past = 0
+            if past > self._vt_upto:   # K/V appended by decode steps have no V^T yet: one transposed copy over all layers
+                a0 = self._vt_upto
+                self.vtc[:, :, :, a0:past] = self.vcache[:, :, a0:past, :].transpose(2, 3)
+        key = (L0 - past, past, sampling)
+        if key not in self._prefill_plans:
+            if len(self._prefill_plans) >= 24:
+                self._prefill_plans.pop(next(iter(self._prefill_plans)))
+            self._prefill_plans[key] = self._build_prefill(L0 - past, sampling, past=past)
+        segs, io = self._prefill_plans[key]
+        io["ids"].copy_(input_ids[0, past:])
+        self._kv_ids, self._vt_upto = None, L0      # (set again once this call's decode steps are known)
         self.ban.copy_(self._ban_mask(bad_words_ids))
         self.st_pos.fill_(L0)
         self.st_step.zero_()
@@ -509,5 +545,8 @@ class USDMForCausalLM:
             for _ in range(n):
                 self._decode.run()
             produced += n
+        if self.reuse_prefix:   # ids whose K/V now sit in the cache: the prompt and every generated token that was fed back
+            fed = self.st_out[:produced - 1].tolist() if produced > 1 else []
+            self._kv_ids = ids_host + fed
         out = torch.cat([input_ids[0], torch.tensor(toks, dtype=torch.long, device=input_ids.device)])
         return out.unsqueeze(0)
