@@ -328,8 +328,11 @@ def main():
     }
     if rank == 0:
         res["roofline"] = measure_gemv_roofline(pipe.llm)
-        if world == 1 and not args.no_batched:
-            res["llm_batched_decode"] = batched_decode_rate(pipe.llm)
+        if world == 1 and not dist_on and not args.no_batched:
+            try:
+                res["llm_batched_decode"] = batched_decode_rate(pipe.llm)
+            except Exception as e:  # noqa: BLE001 - informational field only, must never break the bench line
+                res["llm_batched_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
     elif dist_on:
