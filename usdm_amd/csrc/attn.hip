@@ -15,6 +15,7 @@
 
 namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int KT = 64;  // keys per tile
 
@@ -76,6 +77,17 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
   const float slope = (MODE == 0 && a.slopes) ? a.slopes[h] : 0.f;
   const float sc = a.scale * 1.4426950408889634f;  // scores kept in log2 domain
   const float slope2 = slope * 1.4426950408889634f;
+  // ALiBi term of register pair (r, r+1) of sub-tile u: slope2 * (key offset inside the tile), for the packed fast path
+  f32x2 cb[2][8];
+  if (MODE == 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float c = (float)(32 * u + (r & 3) + 8 * (r >> 2));
+        cb[u][r >> 1] = f32x2{slope2 * c, slope2 * (c + 1.0f)};
+      }
+  }
 
   int kend = kv_len;
   if (MODE == 1) {
@@ -163,6 +175,23 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
     const int kbase = kt * KT + 4 * lh;                       // kpos(u,r) = kbase + 32u + (r&3) + 8(r>>2)
     const float fq = (float)(qpos - kbase);                   // qpos - kpos = fq - c(u,r)
     float mloc = -1e30f;
+    // every key of this tile on one side of every query of this wave (all but <= 2 tiles of a row block): |q - k| has a
+    // fixed sign, so the bias is sg * (A + cb) with A = -slope2 * fq per lane: two packed FMAs per score pair instead of
+    // sub / mul|.| / fma per score (the loop is VALU-issue bound, profiles/r01_gemm_ablation.txt)
+    const int qw0 = a.q_pos0 + q0;
+    const bool k_left = kt * KT + KT - 1 <= qw0, k_right = kt * KT >= qw0 + 31;
+    if (MODE == 0 && (k_left || k_right)) {
+      const float sg = k_left ? 1.0f : -1.0f;
+      const f32x2 sg2 = {sg, sg}, a2 = {-sg * slope2 * fq, -sg * slope2 * fq}, sc2 = {sc, sc};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 bias = __builtin_elementwise_fma(cb[u][r >> 1], sg2, a2);
+          const f32x2 sv = __builtin_elementwise_fma(f32x2{sacc[u][r], sacc[u][r + 1]}, sc2, bias);
+          sacc[u][r] = sv.x; sacc[u][r + 1] = sv.y;
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -173,6 +202,7 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
         else s = sacc[u][r] * sc;
         sacc[u][r] = s;
       }
+    }
     if (MODE == 0 && kt == 0 && a.alibi_col0_zero) {          // key 0 carries no ALiBi bias (networks.py:327)
       if (lh == 0) sacc[0][0] = fmaf(sacc[0][0], 1.0f, slope2 * fabsf(fq));
     }
@@ -195,15 +225,18 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
     const float m_new = fmaxf(m_run, mloc);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float psum = 0.f;
+    f32x2 ps2 = {0.f, 0.f};
+    const f32x2 mn2 = {m_new, m_new};
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[u][r] - m_new);   // masked scores (-1e30) underflow to exactly 0
-        sacc[u][r] = p;
-        psum += p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 dv = f32x2{sacc[u][r], sacc[u][r + 1]} - mn2;      // packed subtract
+        const f32x2 pv = {__builtin_amdgcn_exp2f(dv.x), __builtin_amdgcn_exp2f(dv.y)};   // masked scores (-1e30) underflow to exactly 0
+        sacc[u][r] = pv.x; sacc[u][r + 1] = pv.y;
+        ps2 += pv;
       }
+    const float psum = ps2.x + ps2.y;
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
