@@ -227,6 +227,7 @@ typedef struct usdm_gemv_args {
    * instead of a separate residual-add launch: x' = bf16(x + bf16(x_delta)) is what gets normalised / multiplied, and
    * workgroup 0 writes x' to x_out (a DIFFERENT buffer than x: other workgroups are still reading x) */
   const float* x_delta; void* x_out;
+  const int32_t* skip;  /* optional: *skip != 0 -> the launch returns immediately (see usdm_decode_state.done) */
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
@@ -250,6 +251,11 @@ typedef struct usdm_decode_state {
   int32_t max_out, id_offset, advance_pos;
   int32_t batch;        /* batched decode: 0 or 1 = single; else arrays of `batch` items: next_token[b], step[b], pos[b],
                            out_tokens[b][max_out] */
+  /* device-side end of sequence (optional; all device memory so that a captured graph follows per-call settings):
+   * eos = { n_eos (<= 6), min_new, id0, id1, ... }.  Once the picked token is one of the ids and at least min_new tokens
+   * exist, done[b] is set; later calls with done[b] != 0 return without touching the state.  The decode kernels take
+   * the same word as `skip` and return at once, so steps launched past the EOS cost launch overhead only. */
+  int32_t* done; const int32_t* eos;
 } usdm_decode_state;
 /* arg-max over the per-block partials (ties -> lowest id = torch.argmax on the masked logits; with
  * do_sample=True, top_k=1 the reference samples among exact ties, of which this is one outcome). */
@@ -302,6 +308,7 @@ typedef struct usdm_attn_decode_args {
   /* batched decode: `batch` sequences in one launch (0 or 1 = single).  Item b reads pos[b], qkv + b*qkv_bs, caches +
    * b*cache_bs, writes out + b*out_bs (element strides); scratch is [batch][Hq][NS]...; counters [batch][Hkv]. NS > 1. */
   int32_t batch; int64_t qkv_bs, out_bs, cache_bs;
+  const int32_t* skip;  /* optional (single-sequence form): *skip != 0 -> return immediately */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

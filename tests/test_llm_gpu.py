@@ -227,3 +227,27 @@ def test_prefix_kv_reuse(dev, tp_seg):
     a2 = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw); a2.reuse_prefix = True
     q = torch.randint(0, 1000, (1, 50), generator=g).to(dev)
     assert torch.equal(a2.generate(input_ids=q, max_new_tokens=8), b.generate(input_ids=q, max_new_tokens=8))
+
+
+def test_device_side_eos(dev):
+    """An EOS in the middle of a host chunk of 8 decode steps: the remaining launches of the chunk return at once (the device
+    step counter stops at the EOS), and the result equals the host-only check (more EOS ids than the device list holds)."""
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    sd = MO.random_state_dict(SMALL, seed=31)
+    m = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256)
+    ids = torch.randint(0, 1000, (1, 33), generator=torch.Generator().manual_seed(8)).to(dev)
+    free = m.generate(input_ids=ids, max_new_tokens=40)
+    gen = free[0, 33:].tolist()
+    k = 11                                             # 12th generated token: inside the second chunk (tokens 2..9, 10..17)
+    eos = gen[k]
+    first = gen.index(eos)
+    a = m.generate(input_ids=ids, max_new_tokens=40, eos_token_id=eos)
+    assert a.shape[1] == 33 + first + 1 and a[0, -1].item() == eos
+    assert int(m.st_step.item()) == first + 1          # nothing ran past the EOS
+    host_only = [eos] + [2000 + i for i in range(7)]   # 8 ids > device capacity -> host-side check only
+    b = m.generate(input_ids=ids, max_new_tokens=40, eos_token_id=host_only)
+    assert torch.equal(a, b) and int(m.st_step.item()) >= first + 1
+    # min_new_tokens defers the stop
+    c = m.generate(input_ids=ids, max_new_tokens=40, eos_token_id=eos, min_new_tokens=first + 2)
+    assert c.shape[1] > a.shape[1] and torch.equal(c[0, :a.shape[1]], free[0, :a.shape[1]])

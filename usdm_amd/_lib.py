@@ -108,7 +108,7 @@ class GemvArgs(C.Structure):
         ("act", C.c_int32), ("round_bf16", C.c_int32),
         ("residual", C.c_void_p), ("y16", C.c_void_p), ("y32", C.c_void_p),
         ("ban", C.c_void_p), ("part_val", C.c_void_p), ("part_idx", C.c_void_p), ("idx_offset", C.c_int32),
-        ("x_delta", C.c_void_p), ("x_out", C.c_void_p),
+        ("x_delta", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p),
     ]
 
 
@@ -122,6 +122,7 @@ class DecodeState(C.Structure):
     _fields_ = [
         ("next_token", C.c_void_p), ("out_tokens", C.c_void_p), ("step", C.c_void_p), ("pos", C.c_void_p),
         ("max_out", C.c_int32), ("id_offset", C.c_int32), ("advance_pos", C.c_int32), ("batch", C.c_int32),
+        ("done", C.c_void_p), ("eos", C.c_void_p),
     ]
 
 
@@ -148,7 +149,7 @@ class AttnDecodeArgs(C.Structure):
         ("cos", C.c_void_p), ("sin", C.c_void_p),
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
         ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
-        ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64),
+        ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64), ("skip", C.c_void_p),
     ]
 
 

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   __shared__ float sv[NWV];
   __shared__ int si[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int skipv = a.skip ? *a.skip : 0;   // requested now, tested once the first ring is in flight (no exposed latency)
   GTR(0);
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
       if (u < nit) ring[j][u] = wload(j, u);
 
   GTR(1);
+  if (skipv) return;   // the sequence ended in an earlier step of this host chunk (usdm_decode_state.done)
   // ---- stage x into LDS (optionally fused RMSNorm with HF rounding) while the first ring is in flight
   const bf16_t* xg = (const bf16_t*)a.x;
   // 8 consecutive elements of the input vector; with x_delta the pending residual add of the tensor-parallel path is applied
@@ -250,6 +252,7 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
   __shared__ int si[256];
   __shared__ int s_tok;
   const int b = blockIdx.x;   // sequence of a batched step (grid = 1 when single)
+  if (st.done && st.done[b]) return;
   pv += (int64_t)b * nparts; pi += (int64_t)b * nparts;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
@@ -275,6 +278,12 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
     if (step < st.max_out) st.out_tokens[(int64_t)b * st.max_out + step] = tok;
     st.step[b] = step + 1;
     if (st.advance_pos) st.pos[b] = st.pos[b] + 1;
+    if (st.done && st.eos) {   // device-side EOS: eos = {count, min_new, ids...}
+      const int n = st.eos[0], mn = st.eos[1];
+      bool hit = false;
+      for (int i = 0; i < n && i < 6; ++i) hit |= (st.eos[2 + i] == tok);
+      if (hit && step + 1 >= mn) st.done[b] = 1;
+    }
     s_tok = tok;
   }
   if (E) {  // fused nn.Embedding lookup of the token the next decode step consumes
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   __shared__ float sc[G][DA_KMAX];
   __shared__ float red[8][G][128];
   __shared__ float lsum[G], lmax[G];
+  const int skipv = a.skip ? *a.skip : 0;        // tested after the K/V requests below are issued
   const int kh = blockIdx.x, sp = blockIdx.y, NS = gridDim.y;
   const int bi = blockIdx.z;                      // sequence of a batched decode step (0 when single)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
       rv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
     }
   }
+  if (skipv) return;   // sequence already ended (usdm_decode_state.done): nothing may be appended to the cache
   // ---- rope q (G heads) and the new k; stash v
   for (int i = tid; i < (G + 1) * 64; i += 256) {
     const int hsel = i >> 6, d = i & 63;
@@ -570,6 +581,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
 // ---------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(1024) void attn_decode1_kernel(const usdm_attn_decode_args a) {
+  if (a.skip && *a.skip) return;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   float* sc = (float*)dsm;                          // [G][ctx_pad]
   const int pos = *a.pos;
@@ -712,7 +724,8 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const usdm_attn_deco
 }
 
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* pm, const float* pl, const float* po, int NS, bf16_t* out,
-                                                           int64_t out_bs) {
+                                                           int64_t out_bs, const int* skip) {
+  if (skip && *skip) return;
   __shared__ float w[64];
   __shared__ float linv;
   const int hq = blockIdx.x, d = threadIdx.x;  // 128 threads
@@ -874,7 +887,7 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
   USDM_LAUNCH_CHECK();
   if (!a.counters) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq, nbatch), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out, a.out_bs);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq, nbatch), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out, a.out_bs, a.skip);
     USDM_LAUNCH_CHECK();
   }
   return 0;

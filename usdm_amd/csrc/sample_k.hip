@@ -57,6 +57,7 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
   __shared__ unsigned long long s_rem;
   __shared__ int s_tok;
   const int tid = threadIdx.x, V = a.V;
+  if (st.done && *st.done) return;
   const float invT = 1.0f / a.temperature;   // HF divides; x / T and x * (1 / T) differ by <= 1 ulp, below the logits' bf16 grain
   auto X = [&](int i) { return a.logits[i] * invT; };
 
@@ -195,6 +196,12 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
     if (step < st.max_out) st.out_tokens[step] = tok;
     *st.step = step + 1;
     if (st.advance_pos) *st.pos = *st.pos + 1;
+    if (st.done && st.eos) {   // device-side EOS: eos = {count, min_new, ids...}
+      const int n = st.eos[0], mn = st.eos[1];
+      bool hit = false;
+      for (int i = 0; i < n && i < 6; ++i) hit |= (st.eos[2 + i] == tok);
+      if (hit && step + 1 >= mn) *st.done = 1;
+    }
   }
   if (E) {
     const u32x4* src = (const u32x4*)(E + (int64_t)(s_tok + st.id_offset) * Hd);

@@ -169,6 +169,9 @@ class USDMForCausalLM:
         self.max_out = self.ctx_max
         self.st_next, self.st_step, self.st_pos = i32(1), i32(1), i32(1)
         self.st_out = i32(self.max_out)
+        # device-side end of sequence: st_eos = {count, min_new, ids...}; st_done is set by the token-picking kernel and read by
+        # every decode kernel as its skip word, so steps launched past an EOS inside a host chunk return immediately
+        self.st_done, self.st_eos = i32(1), i32(8)
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
         self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
@@ -188,7 +191,7 @@ class USDMForCausalLM:
         dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
         dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
 
-    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None, slot=None):
+    def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None, slot=None, skip=None):
         """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
         sampling=(temperature, top_k, top_p, seed): usdm_sample_final over the ban-masked logits."""
         c = self.cfg
@@ -198,8 +201,10 @@ class USDMForCausalLM:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
                  y32=self.last_logits if want_logits else None, ban=self.ban, part_val=sl.part_val_loc, part_idx=sl.part_idx_loc, idx_offset=self.v0,
-                 x_delta=x_delta, plan=plan)
-        st = ops.decode_state(sl.st_next, sl.st_out, sl.st_step, sl.st_pos, advance_pos=advance_pos)
+                 x_delta=x_delta, skip=skip, plan=plan)
+        single = sl is self
+        st = ops.decode_state(sl.st_next, sl.st_out, sl.st_step, sl.st_pos, advance_pos=advance_pos,
+                              done=self.st_done if single else None, eos=self.st_eos if single else None)
         if sampling is not None:
             if self.tp_path:
                 raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
@@ -297,19 +302,21 @@ class USDMForCausalLM:
         def flip(cur):
             return h_alt if cur is self.h_dec else self.h_dec
 
+        skp = self.st_done   # decode kernels return at once after a device-side EOS (see _alloc)
+
         for l in range(L):   # h already holds the embedding of the current token (written by usdm_argmax_final)
             w = self.W["layers"][l]
             if pend is not None:
-                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, x_delta=pend, x_out=flip(h), plan=plan)
+                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, x_delta=pend, x_out=flip(h), skip=skp, plan=plan)
                 h, pend = flip(h), None
             else:
-                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
+                ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, plan=plan)
             if tp == 1:
-                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, plan=plan)
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, plan=plan)
             else:
-                ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, plan=plan)
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, skip=skp, plan=plan)
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
                 if fuse_res:
@@ -318,14 +325,14 @@ class USDMForCausalLM:
                     ops.residual_add(h, part, H, plan=plan)
             if pend is not None:
                 ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, x_delta=pend,
-                         x_out=flip(h), plan=plan)
+                         x_out=flip(h), skip=skp, plan=plan)
                 h, pend = flip(h), None
             else:
-                ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, plan=plan)
+                ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, skip=skp, plan=plan)
             if tp == 1:
-                ops.gemv(w["down"], act, N=H, K=I, residual=h, y16=h, plan=plan)
+                ops.gemv(w["down"], act, N=H, K=I, residual=h, y16=h, skip=skp, plan=plan)
             else:
-                ops.gemv(w["down"], act, N=H, K=I, round_bf16=False, y32=part2, plan=plan)
+                ops.gemv(w["down"], act, N=H, K=I, round_bf16=False, y32=part2, skip=skp, plan=plan)
                 segs += [plan, (lambda t=part2: self._all_reduce(t))]
                 plan = ops.Plan()
                 if fuse_res:
@@ -333,9 +340,9 @@ class USDMForCausalLM:
                 else:
                     ops.residual_add(h, part2, H, plan=plan)
         if pend is not None:   # the last down-projection's sum goes into the final norm + lm_head
-            self._lm_head_and_pick(plan, h, True, segs, sampling, x_delta=pend)
+            self._lm_head_and_pick(plan, h, True, segs, sampling, x_delta=pend, skip=skp)
         else:
-            self._lm_head_and_pick(plan, h, True, segs, sampling)
+            self._lm_head_and_pick(plan, h, True, segs, sampling, skip=skp)
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs
 
@@ -524,6 +531,10 @@ class USDMForCausalLM:
         self.ban.copy_(self._ban_mask(bad_words_ids))
         self.st_pos.fill_(L0)
         self.st_step.zero_()
+        eos_list = sorted(set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])) if eos_token_id is not None else []
+        dev_eos = eos_list if len(eos_list) <= 6 else []      # more ids than the device list holds: host-side check only
+        self.st_eos.copy_(torch.tensor(([len(dev_eos), int(min_new_tokens)] + dev_eos + [0] * 6)[:8], dtype=torch.int32))
+        self.st_done.zero_()
         self._run_segs(segs)  # prefill + first token
         if sampling not in self._decodes:
             dsegs = self._build_decode(sampling)
@@ -533,6 +544,8 @@ class USDMForCausalLM:
         produced, done, chunk = 1, False, 8
         toks = []
         while True:
+            n_dev = int(self.st_step.item()) if dev_eos else produced   # steps past a device-side EOS did not run
+            produced = min(produced, n_dev)
             toks = self.st_out[:produced].tolist()  # host sync point (EOS check)
             hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
             if hit:

@@ -208,9 +208,9 @@ def process_unit(units, rep, hop):
 
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
-         ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, plan=None):
+         ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, plan=None):
     """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h)."""
-    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out)
+    _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out, skip)
     if x_out is not None and x_out.data_ptr() == x.data_ptr():
         raise ValueError("usdm_gemv: x_out must not alias x")
     a = GemvArgs()
@@ -219,16 +219,18 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     a.act, a.round_bf16 = act, int(round_bf16)
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
-    a.x_delta, a.x_out = _ptr(x_delta), _ptr(x_out)
+    a.x_delta, a.x_out, a.skip = _ptr(x_delta), _ptr(x_out), _ptr(skip)
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
 
 
-def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True, batch=0):
-    """batch > 1: next_token / step / pos are [batch] and out_tokens is [batch][max_out]."""
+def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True, batch=0, done=None, eos=None):
+    """batch > 1: next_token / step / pos are [batch] and out_tokens is [batch][max_out].
+    done [1] / eos [8] = {n_eos, min_new, ids...}: device words of the optional device-side end of sequence."""
     st = DecodeState()
     st.next_token, st.out_tokens, st.step, st.pos = _ptr(next_token), _ptr(out_tokens), _ptr(step), _ptr(pos)
     st.max_out = out_tokens.shape[-1] if batch > 1 else out_tokens.numel()
     st.id_offset, st.advance_pos, st.batch = id_offset, int(advance_pos), batch
+    st.done, st.eos = _ptr(done), _ptr(eos)
     return st
 
 
@@ -276,13 +278,13 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
 
 
 def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,
-                qkv_bs=0, out_bs=0, cache_bs=0, plan=None):
+                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, plan=None):
     _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
     a.cos, a.sin, a.kcache, a.vcache = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache)
     a.pm, a.pl, a.po, a.out, a.counters = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out), _ptr(counters)
-    a.batch, a.qkv_bs, a.out_bs, a.cache_bs = batch, qkv_bs, out_bs, cache_bs
+    a.batch, a.qkv_bs, a.out_bs, a.cache_bs, a.skip = batch, qkv_bs, out_bs, cache_bs, _ptr(skip)
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
