@@ -1,7 +1,23 @@
 """hipGraph capture of a recorded launch plan (torch.cuda.CUDAGraph is hipGraph on ROCm)."""
+import contextlib
+import gc
 import os
 
 import torch
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """Python's cyclic GC must not run while a stream is capturing: collecting an old hipGraph / tensor there issues HIP
+    calls that are illegal during capture and abort the process (seen once in the full GPU test run)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphedPlan:
@@ -23,7 +39,7 @@ class GraphedPlan:
             # capture outside inference mode: the RNG bookkeeping tensors torch registers at the first capture must
             # not become inference tensors (callers such as reconstruct_speech run under @torch.inference_mode()),
             # or a later capture outside inference mode fails with "Inplace update to inference tensor"
-            with torch.inference_mode(False):
+            with torch.inference_mode(False), _no_gc():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self.plan.run()
@@ -52,7 +68,7 @@ class GraphedSegments:
             return
         if self.graph is None:
             try:
-                with torch.inference_mode(False):
+                with torch.inference_mode(False), _no_gc():
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self.run_segs(self.segs)
