@@ -116,6 +116,13 @@ class Pipeline:
                 "voicebox_vocoder": g("llm3", "dec")}
 
 
+def gemv_rows(llm, a):
+    """Rows a usdm_gemv launch has to stream: all of them, except in lm_head mode where rows whose id is banned are skipped."""
+    if a.part_val and a.ban:
+        return int((llm.ban == 0).sum().item())
+    return a.N
+
+
 def measure_gemv_roofline(llm):
     """Eager pass over one decode step with a HIP-event pair around every usdm_gemv launch (same stream)."""
     from usdm_amd import ops
@@ -136,7 +143,7 @@ def measure_gemv_roofline(llm):
                     fn(*args, stream)
                     e1.record()
                     pairs.append((e0, e1))
-                    nbytes += 2 * a.N * a.K
+                    nbytes += 2 * gemv_rows(llm, a) * a.K
                 else:
                     fn(*args, stream)
         torch.cuda.synchronize()

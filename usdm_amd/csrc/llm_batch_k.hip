@@ -51,7 +51,29 @@ __global__ __launch_bounds__(NWV * 64) void gemv_batch_kernel(const usdm_gemv_ba
     wp[j] = (const u32x4*)((const bf16_t*)a.W + (int64_t)r * a.ldw) + lane;
   }
   const bool tail_ok = ((nit - 1) << 9) + lane * 8 < K;
+  // lm_head mode: rows of banned ids are not streamed (see gemv_kernel)
+  bool active = true;
+  if (a.part_val && a.ban) {
+    const int wb = blockIdx.x * rows_per_block;
+    bool wg_active = false;
+    for (int r = wb; r < wb + rows_per_block && r < a.N; ++r) wg_active |= (a.ban[r] == 0);
+    if (!wg_active) {
+      if (tid < NB) {
+        a.part_val[(int64_t)tid * ba.part_bs + blockIdx.x] = -INFINITY;
+        a.part_idx[(int64_t)tid * ba.part_bs + blockIdx.x] = 0x7fffffff;
+      }
+      if (a.y32 && tid < rows_per_block && wb + tid < a.N)
+        for (int b = 0; b < NB; ++b) a.y32[(int64_t)b * ba.y_bs + wb + tid] = -INFINITY;
+      return;
+    }
+    active = false;
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      if (ob + j < a.N) active |= (a.ban[ob + j] == 0);
+    active = __builtin_amdgcn_readfirstlane(active);
+  }
   auto wload = [&](int j, int it) -> u32x4 {
+    if (!active) return u32x4{0u, 0u, 0u, 0u};
     const u32x4* p = (it == nit - 1 && !tail_ok) ? wp[j] - lane : wp[j] + it * 64;
     return __builtin_nontemporal_load(p);
   };

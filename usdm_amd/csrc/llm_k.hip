@@ -75,7 +75,27 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     wp[j] = (const u32x4*)((const bf16_t*)a.W + (int64_t)r * a.ldw) + lane;
   }
   const bool tail_ok = ((nit - 1) << 9) + lane * 8 < K;  // is this lane inside K on the last iteration?
+  // lm_head mode: a wave whose rows are ALL banned (the reference's bad_words_ids mask whole id ranges: 76 % of the vocabulary
+  // in the text->unit round, inference.py:51-53) streams nothing; its logits are -inf either way
+  bool active = true;
+  if (a.part_val && a.ban) {
+    // whole workgroup banned: publish "no candidate" and leave before anything is staged (no barrier has been reached yet)
+    const int wb = blockIdx.x * rows_per_block;
+    bool wg_active = false;
+    for (int r = wb; r < wb + rows_per_block && r < a.N; ++r) wg_active |= (a.ban[r] == 0);
+    if (!wg_active) {
+      if (tid == 0) { a.part_val[blockIdx.x] = -INFINITY; a.part_idx[blockIdx.x] = 0x7fffffff; }
+      if (a.y32 && tid < rows_per_block && wb + tid < a.N) a.y32[wb + tid] = -INFINITY;
+      return;
+    }
+    active = false;
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      if (ob + j < a.N) active |= (a.ban[ob + j] == 0);
+    active = __builtin_amdgcn_readfirstlane(active);
+  }
   auto wload = [&](int j, int it) -> u32x4 {
+    if (!active) return u32x4{0u, 0u, 0u, 0u};
     // last iteration may run past K: redirect to the row start (x is zero there in LDS, contributes 0)
     const u32x4* p = (it == nit - 1 && !tail_ok) ? wp[j] - lane : wp[j] + it * 64;
     return __builtin_nontemporal_load(p);
