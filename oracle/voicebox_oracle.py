@@ -134,7 +134,7 @@ def cfg_velocity(sd, cfg, x, z, cond, lengths, t, gradient_scale, speech_prompt,
 
 
 def generate(sd, cfg, x, cond, lengths, n_timesteps, noise, solver="euler", gradient_scale=0.0,
-             speech_prompt=False, prompt_lengths=None, f=None):
+             speech_prompt=False, prompt_lengths=None, f=None, trace=None):
     """voicebox.py:140-150 + solve_euler :74-99 / solve_heun :101-138.
 
     `noise` is the list of N(0,1) tensors the reference would draw with randn_like, in call order:
@@ -153,7 +153,11 @@ def generate(sd, cfg, x, cond, lengths, n_timesteps, noise, solver="euler", grad
         zz[:, :, :P] = pr[:, :, :P]
         return zz
 
-    vel = lambda zz, tt: cfg_velocity(sd, cfg, x, zz, cond, lengths, tt, gradient_scale, speech_prompt, f)
+    def vel(zz, tt):
+        v = cfg_velocity(sd, cfg, x, zz, cond, lengths, tt, gradient_scale, speech_prompt, f)
+        if trace is not None:      # per-NFE velocities (tests print the error growth over chained NFEs)
+            trace.append(v.clone())
+        return v
     steps = 1
     while steps <= len(t_span) - 1:
         v = vel(z, t)

@@ -1,0 +1,39 @@
+"""Shared checker: greedy ids of the HIP LLM vs the CPU oracle, continuing past legitimate divergences.
+
+A divergence is legitimate only at a near-tie of the ORACLE's own bf16 logits (top-2 gap within bf16 noise of the logit
+magnitude).  After one, the HIP model is re-prompted with the oracle's tokens up to and including the diverging position
+(teacher forcing through the prefill path) so that the rest of the sequence is still compared token by token."""
+import torch
+
+NEAR_TIE_REL = 2 ** -6      # two bf16 ulps of the top logit
+NEAR_TIE_ABS = 1e-3
+
+
+def compare_greedy(model, dev, ids, ref, ref_logits, new, max_restarts=8, **gen_kw):
+    """ids: int64 [L0] prompt; ref: oracle id list (prompt + new); ref_logits: [new, V] masked oracle logits.
+    Returns (list of diverging generated-token indices, number of tokens compared)."""
+    L0 = ids.numel()
+    ref_gen = ref[L0:]
+    assert len(ref_gen) == new
+    done, div = 0, []
+    while done < new:
+        prompt = torch.tensor(ref[:L0 + done], dtype=torch.long)[None].to(dev)
+        out = model.generate(input_ids=prompt, max_new_tokens=new - done, **gen_kw)[0].tolist()
+        assert out[:L0 + done] == ref[:L0 + done]
+        gen = out[L0 + done:]
+        assert len(gen) == new - done
+        first = next((i for i in range(len(gen)) if gen[i] != ref_gen[done + i]), None)
+        if first is None:
+            done = new
+            break
+        j = done + first
+        top2 = torch.topk(ref_logits[j], 2).values
+        gap = (top2[0] - top2[1]).item()
+        assert gap <= NEAR_TIE_REL * top2[0].abs().item() + NEAR_TIE_ABS, \
+            f"generated token {j}: HIP {gen[first]} vs oracle {ref_gen[j]} with oracle top-2 gap {gap} (not a near-tie)"
+        # the HIP choice must be the oracle's runner-up (the other side of the tie)
+        assert gen[first] == int(torch.topk(ref_logits[j], 2).indices[1]), f"token {j}: HIP picked neither of the oracle's top 2"
+        div.append(j)
+        assert len(div) <= max_restarts, f"too many near-tie divergences: {div}"
+        done = j + 1
+    return div, new

@@ -75,3 +75,78 @@ def test_tp2_gloo_matches_unsharded():
     for p in procs:
         p.join(30)
     assert all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
+
+
+def _emulate_lm_head_partials(logits_loc, v0, nparts):
+    """What usdm_gemv's lm_head mode leaves in this rank's partial buffers: one (max, global id) per block of 16 rows,
+    ties -> lowest id; slots past the shard's last block keep the (-inf, 0x7fffffff) fill (llm.py _alloc)."""
+    from usdm_amd.llm import NO_CANDIDATE_IDX
+    pv = torch.full((nparts,), float("-inf"))
+    pi = torch.full((nparts,), NO_CANDIDATE_IDX, dtype=torch.int32)
+    n = logits_loc.numel()
+    for b in range((n + 15) // 16):
+        blk = logits_loc[16 * b:16 * b + 16]
+        j = int(torch.argmax(blk))            # first maximum = lowest id
+        pv[b], pi[b] = blk[j], v0 + 16 * b + j
+    return pv, pi
+
+
+def _final_argmax(pv, pi):
+    """argmax_final_kernel's rule: largest value, ties -> lowest id."""
+    best = max(range(pv.numel()), key=lambda i: (pv[i].item(), -int(pi[i])))
+    return int(pi[best])
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_vocab_parallel_partials_have_equal_size_on_every_rank(tp):
+    """with V = 42 003 and tp = 8 the last rank owns 5246 rows instead of 5251; the arg-max partial buffers
+    that are all-gathered must still have ONE size, and the unused tail slots must never win (all logits negative here, so
+    a zero-initialised slot WOULD win)."""
+    from usdm_amd.llm import vocab_shard
+    V = 42003
+    logits = -torch.rand(V, generator=torch.Generator().manual_seed(tp)) - 0.5     # all negative
+    logits[V - 3] = -0.25                                                           # the winner lives in the LAST rank's shard
+    shards = [vocab_shard(V, r, tp) for r in range(tp)]
+    assert len({s[3] for s in shards}) == 1 and len({s[0] for s in shards}) == 1     # nparts and Vloc equal on every rank
+    assert shards[0][1] == 0 and shards[-1][2] == V and all(shards[r][2] == shards[r + 1][1] for r in range(tp - 1))
+    nparts = shards[0][3]
+    gathered_v, gathered_i = [], []
+    for Vloc, v0, v1, _ in shards:
+        assert v1 - v0 <= Vloc and (v1 - v0 + 15) // 16 <= nparts
+        pv, pi = _emulate_lm_head_partials(logits[v0:v1], v0, nparts)
+        assert pv.numel() == pi.numel() == nparts
+        gathered_v.append(pv); gathered_i.append(pi)
+    got = _final_argmax(torch.cat(gathered_v), torch.cat(gathered_i))
+    assert got == int(torch.argmax(logits)) == V - 3
+    if tp == 8:
+        assert shards[-1][2] - shards[-1][1] == 5246 and shards[0][0] == 5251 and nparts == 329
+
+
+def _gather_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from usdm_amd.llm import vocab_shard
+    V = 4099                                                    # odd split: rank 1 is one row short
+    logits = -torch.rand(V, generator=torch.Generator().manual_seed(5)) - 0.5
+    logits[V - 1] = -0.1
+    Vloc, v0, v1, nparts = vocab_shard(V, rank, world)
+    pv, pi = _emulate_lm_head_partials(logits[v0:v1], v0, nparts)
+    allv, alli = torch.empty(nparts * world), torch.empty(nparts * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(allv, pv)                       # the call llm._gather_partials makes (equal counts required)
+    dist.all_gather_into_tensor(alli, pi)
+    out_q.put((rank, _final_argmax(allv, alli) == int(torch.argmax(logits)), True, True))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_tp2_gloo_gather_of_partials_with_uneven_vocab_split():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] for r in res), res

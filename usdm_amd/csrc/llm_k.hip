@@ -292,7 +292,8 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const int tok = si[0] + st.id_offset;
+    // every id banned (no candidate anywhere): fall back to id 0 so that nothing indexes the embedding table out of range
+    const int tok = (si[0] == 0x7fffffff ? 0 : si[0]) + st.id_offset;
     const int step = st.step[b];
     st.next_token[b] = tok;
     if (step < st.max_out) st.out_tokens[(int64_t)b * st.max_out + step] = tok;

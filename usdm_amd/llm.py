@@ -31,15 +31,27 @@ def _pack_gate_up(gate, up):
     return torch.stack([gate.reshape(I // 16, 16, K), up.reshape(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous()
 
 
+def vocab_shard(V, rank, tp):
+    """Vocab-parallel lm_head layout: (Vloc, v0, v1, nparts).  Every rank owns Vloc = ceil(V/tp) row SLOTS (the last rank
+    fewer real rows: 42 003 / 8 -> 7 x 5251 + 5246) and nparts = usdm_gemv_nblocks(Vloc) arg-max partial slots, so the
+    partial buffers that are exchanged have the SAME size on every rank (a collective with per-rank counts that differ is
+    undefined behaviour in RCCL); unused slots keep their (-inf, 0x7fffffff) fill and can never win."""
+    Vloc = (V + tp - 1) // tp
+    v0 = min(V, rank * Vloc)
+    v1 = min(V, v0 + Vloc)
+    return Vloc, v0, v1, ops.gemv_nblocks(Vloc)
+
+
+NO_CANDIDATE_IDX = 0x7fffffff
+
+
 def shard_weights(sd_get, cfg, rank, tp, device, dtype=torch.bfloat16):
     """This rank's packed weights for tensor parallelism of degree `tp` (Megatron-style): q/k/v heads and MLP
     columns split by rank, o_proj/down_proj split along K (their outputs are partial sums), vocab rows split."""
     d = cfg["head_dim"]
     Hq, Hkv, I = cfg["num_attention_heads"] // tp, cfg["num_key_value_heads"] // tp, cfg["intermediate_size"] // tp
     V = cfg["vocab_size"]
-    Vloc = (V + tp - 1) // tp
-    v0 = min(V, rank * Vloc)
-    v1 = min(V, v0 + Vloc)
+    _, v0, v1, _ = vocab_shard(V, rank, tp)
     g = lambda n: sd_get(n).to(device, dtype)
     f = lambda n: sd_get(n).to(device, torch.float32).contiguous()
     W = {"embed": g("model.embed_tokens.weight").contiguous(), "norm": f("model.norm.weight"),
@@ -79,9 +91,7 @@ class USDMForCausalLM:
         if self.I * tp_size != c["intermediate_size"] or self.I % 16:
             raise ValueError("intermediate_size / tp_size must be a multiple of 16")
         V = c["vocab_size"]
-        self.Vloc = (V + tp_size - 1) // tp_size
-        self.v0 = min(V, tp_rank * self.Vloc)
-        self.v1 = min(V, self.v0 + self.Vloc)
+        self.Vloc, self.v0, self.v1, self.nparts = vocab_shard(V, tp_rank, tp_size)
         self.ctx_max = (ctx_max + 63) // 64 * 64
         import os
         # decode attention: 1 = one 16-wave workgroup per kv head (no partials / combine launch); >1 = context split
@@ -175,11 +185,13 @@ class USDMForCausalLM:
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
         self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
-        self.nparts = ops.gemv_nblocks(self.v1 - self.v0)
-        self.part_val = torch.zeros(self.nparts * self.tp_size, dtype=torch.float32, device=dev)
-        self.part_idx = torch.zeros(self.nparts * self.tp_size, dtype=torch.int32, device=dev)
-        self.part_val_loc = torch.zeros(self.nparts, dtype=torch.float32, device=dev) if self.tp_path else self.part_val
-        self.part_idx_loc = torch.zeros(self.nparts, dtype=torch.int32, device=dev) if self.tp_path else self.part_idx
+        # arg-max partials: nparts slots per rank, the same on every rank (vocab_shard); slots the lm_head launch does not
+        # write (last rank's shorter shard) stay "no candidate"
+        nv = lambda n: torch.full((n,), float("-inf"), dtype=torch.float32, device=dev)
+        ni = lambda n: torch.full((n,), NO_CANDIDATE_IDX, dtype=torch.int32, device=dev)
+        self.part_val, self.part_idx = nv(self.nparts * self.tp_size), ni(self.nparts * self.tp_size)
+        self.part_val_loc = nv(self.nparts) if self.tp_path else self.part_val
+        self.part_idx_loc = ni(self.nparts) if self.tp_path else self.part_idx
 
     # ------------------------------------------------------------------ collectives (TP only)
     def _all_reduce(self, t):

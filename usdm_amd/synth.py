@@ -55,6 +55,31 @@ def make_unit_extractor(dev, cfg=None, n_layers=35, seed=1, cseed=2):
     return UnitExtractor(None, None, device=dev, config=cfg, state_dict=sd, centroids=cen)
 
 
+def random_llm_state_dict(cfg, dev, seed=3, norm_jitter=0.1):
+    """Full HF-named Mistral state dict, bf16, generated ON the device in a fixed key order (tests hand a .cpu() copy of the
+    SAME tensors to the CPU oracle: generating 7.3 B normals on the host would take minutes)."""
+    c, d = cfg, cfg["head_dim"]
+    H, I, V = c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+    nh, nkv = c["num_attention_heads"], c["num_key_value_heads"]
+    g = _gen(dev, seed)
+    bf = torch.bfloat16
+    r = lambda o, i, sc: (torch.randn(o, i, device=dev, generator=g) * sc).to(bf)
+    n = lambda: (1 + norm_jitter * torch.randn(H, device=dev, generator=g)).to(bf)
+    sd = {"model.embed_tokens.weight": r(V, H, 1.0), "lm_head.weight": r(V, H, H ** -0.5), "model.norm.weight": n()}
+    for l in range(c["num_hidden_layers"]):
+        p = f"model.layers.{l}."
+        sd[p + "self_attn.q_proj.weight"] = r(nh * d, H, H ** -0.5)
+        sd[p + "self_attn.k_proj.weight"] = r(nkv * d, H, H ** -0.5)
+        sd[p + "self_attn.v_proj.weight"] = r(nkv * d, H, H ** -0.5)
+        sd[p + "self_attn.o_proj.weight"] = r(H, nh * d, (nh * d) ** -0.5)
+        sd[p + "mlp.gate_proj.weight"] = r(I, H, H ** -0.5)
+        sd[p + "mlp.up_proj.weight"] = r(I, H, H ** -0.5)
+        sd[p + "mlp.down_proj.weight"] = r(H, I, I ** -0.5)
+        sd[p + "input_layernorm.weight"] = n()
+        sd[p + "post_attention_layernorm.weight"] = n()
+    return sd
+
+
 def make_llm(dev, cfg=None, seed=3, **kw):
     return USDMForCausalLM.random_init(dict(cfg or MISTRAL_7B_USDM), dev, seed=seed, **kw)
 

@@ -34,9 +34,10 @@ class CFM(BaseModule):
 
     @torch.no_grad()
     def generate(self, x, cond, cond_lengths, n_timesteps, solver="euler", gradient_scale=0.0, speech_prompt=False,
-                 prompt_lengths=None, noise=None):
+                 prompt_lengths=None, noise=None, trace=None):
         """x int64 [B,S], cond f32 [B,80,S], cond_lengths int64 [B] -> f32 [B,80,S]
-        (reference: voicebox.py:140-150 with solve_euler :74-99 / solve_heun :101-138 and the CFG of :51-72)."""
+        (reference: voicebox.py:140-150 with solve_euler :74-99 / solve_heun :101-138 and the CFG of :51-72).
+        trace (tests only): a list that receives a copy of the raw estimator output of every NFE."""
         if solver not in ("euler", "heun"):
             return None  # the reference falls through and returns None for unknown solvers
         if not cond.is_cuda:
@@ -76,6 +77,8 @@ class CFM(BaseModule):
         common = dict(B=B, F=F_, S=S, cfg=cfg, gs=float(gradient_scale), z_in=io["y"], t_cur=io["t"], t_count=Bx, cond=condf, P=P)
         for steps in range(1, n + 1):
             gp.run()
+            if trace is not None:
+                trace.append(io["out"].clone())
             t = t + dt
             c_eps, c_cond = float(1 - (1 - self.sigma_min) * t), float(t)
             last = steps == n
@@ -87,6 +90,8 @@ class CFM(BaseModule):
                                z_commit=None if do_corr else Z, t_next=float(t), **common)
             if do_corr:
                 gp.run()
+                if trace is not None:
+                    trace.append(io["out"].clone())
                 eps = None
                 if speech_prompt:
                     eps, k = noise[k], k + 1
