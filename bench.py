@@ -282,14 +282,46 @@ def batched_decode_rate(llm, B=4, new_tokens=96):
             "note": "aggregate over the batch; decode steps only"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed directly (no RANK in the environment): this process has made NO GPU call yet (importing
+    torch does not initialise HIP), so it starts the N ranks as fresh child processes through torch.distributed.run, lets them
+    inherit stdout (rank 0 prints the JSON line) and exits with the launcher's code.  Never an exec of a GPU-holding process."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(rank, world):
+    """USDM_BENCH_LAUNCH_CHECK=1 (CPU test of the launch plumbing, tests/test_bench_launch_cpu.py): rendezvous over gloo, barrier,
+    rank 0 prints one JSON line.  No GPU, no model."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "sum": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("USDM_BENCH_LAUNCH_CHECK") == "1":
+        return launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)

@@ -228,6 +228,13 @@ typedef struct usdm_gemv_args {
    * workgroup 0 writes x' to x_out (a DIFFERENT buffer than x: other workgroups are still reading x) */
   const float* x_delta; void* x_out;
   const int32_t* skip;  /* optional: *skip != 0 -> the launch returns immediately (see usdm_decode_state.done) */
+  /* tensor-parallel decode over xGMI peer-to-peer (usdm_allreduce_p2p_*, below): this launch is a ROW-parallel projection
+   * whose f32 partial sums are all-reduced INSIDE its epilogue.  p2p_mode 1 (fused): the workgroup that owns output rows
+   * [r0, r1) writes its partials as {epoch, f32} granules into slot[site][rank] of EVERY rank's buffer, waits (bounded) for
+   * the same rows from every rank in its own buffer, sums them in rank order and stores y16[n] = bf16(residual[n] +
+   * bf16(sum)): the all-reduce, the residual add and the bf16 rounding of HF's residual stream in one epilogue, no
+   * collective launch.  p2p_mode 2 (split): write only; usdm_allreduce_p2p_reduce finishes.  Needs residual and y16. */
+  const struct usdm_p2p_dev* p2p; int32_t p2p_site, p2p_mode;
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
@@ -269,12 +276,21 @@ int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t np
  * exposes, streamlit_demo.py:201-211) and one multinomial draw with Philox4x32-10(seed, counter = *st->step).
  * logits: f32 [V] of this step with banned ids = -inf (usdm_gemv lm_head mode writes exactly that into y32).
  * top_k = 0 and top_p = 1 switch the filters off.  Ties at a filter boundary are kept or dropped as a block (HF's
- * unstable sort picks arbitrarily).  probs_out (optional, [V]) receives the filtered, renormalised distribution. */
+ * unstable sort picks arbitrarily).  probs_out (optional, [V]) receives the filtered, renormalised distribution.
+ * If no id has positive mass (every logit banned or NaN) the arg-max of the finite logits is taken, else id 0: the
+ * kernel never emits an id outside [0, V). */
+typedef struct usdm_sample_params {   /* the per-request knobs (vLLM SamplingParams of inference_vllm.py:42-66) */
+  float temperature; int32_t top_k; float top_p; int32_t reserved;
+  uint64_t seed;
+} usdm_sample_params;
 typedef struct usdm_sample_args {
   const float* logits; int32_t V;
   float temperature; int32_t top_k; float top_p;
   uint64_t seed;
   float* probs_out;
+  /* optional DEVICE copy of the knobs: when non-NULL it overrides temperature / top_k / top_p / seed above, so that one
+   * captured decode graph serves every request (the host rewrites 24 bytes instead of re-capturing per seed). */
+  const usdm_sample_params* dev_params;
 } usdm_sample_args;
 int usdm_sample_final(const usdm_sample_args* args, const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd,
                       void* h_out_bf16, usdm_stream_t stream);
@@ -311,6 +327,55 @@ typedef struct usdm_attn_decode_args {
   const int32_t* skip;  /* optional (single-sequence form): *skip != 0 -> return immediately */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One-shot peer-to-peer all-reduce for the tensor-parallel decode step (replaces the single-GPU
+ * model.generate of src/inference.py:116-123 when the 7B is sharded over the 8 GPUs of a node).  Messages are 4096 f32
+ * (16 KB): pure latency, so there is no ring and no collective kernel: every rank WRITES its partial rows straight into
+ * every peer's buffer over xGMI (hipIpc-mapped, uncached device memory) as 8-byte granules {tag = epoch, f32 value} -
+ * the data is its own flag (one aligned 8-byte system-scope store is never torn), so no fence, no counter and no
+ * separate flag store are needed; the reader polls its OWN memory.
+ *
+ *   buffer of one rank:  [256-B header: epoch u32, err u32][parity 2][site n_sites][src rank 8][max_elems] granules
+ *   epoch   : device word, starts at 1, +1 per decode step (usdm_argmax_p2p), so a captured hipGraph replays correctly
+ *   parity  : epoch & 1 selects the half; together with the all-to-all of usdm_argmax_p2p once per token no slot is
+ *             rewritten before every reader has left it
+ *   waits   : every poll is BOUNDED (timeout_ms of the 100 MHz wall clock); on expiry the kernel ORs a code into the
+ *             err word and carries on with zeros; once err != 0 no kernel waits again, so a protocol bug costs one
+ *             timeout and surfaces as usdm_allreduce_p2p_error() != 0 - never as a hang
+ *   order   : partials are summed in rank order 0..world-1 on every rank -> bit-identical results on all ranks
+ * Host protocol: create -> export (64-byte hipIpcMemHandle) -> exchange handles by any host channel -> import each
+ * peer (other process) or attach (same process, logical ranks) -> commit.  RCCL stays the prefill / validation path.
+ * ---------------------------------------------------------------------------------------------- */
+enum { USDM_P2P_MAX_RANKS = 8, USDM_P2P_HANDLE_BYTES = 64, USDM_P2P_HEADER_BYTES = 256 };
+enum { USDM_P2P_ERR_TIMEOUT_ROWS = 1, USDM_P2P_ERR_TIMEOUT_PICK = 2, USDM_P2P_ERR_TIMEOUT_REDUCE = 4 };
+typedef struct usdm_p2p_dev {          /* device-visible view (device memory, constant after commit) */
+  uint64_t base[8];                    /* address of rank r's buffer as mapped in THIS process; base[rank] = local */
+  int32_t rank, world, n_sites, max_elems;
+  uint64_t timeout_ticks;              /* 100 MHz ticks */
+} usdm_p2p_dev;
+typedef struct usdm_p2p usdm_p2p;      /* opaque host handle */
+int64_t usdm_allreduce_p2p_bytes(int32_t n_sites, int32_t max_elems);   /* buffer size of one rank (layout above) */
+int usdm_allreduce_p2p_create(int32_t rank, int32_t world, int32_t n_sites, int32_t max_elems, int32_t timeout_ms,
+                              usdm_p2p** out);
+int usdm_allreduce_p2p_export(const usdm_p2p* c, void* handle64);                    /* host bytes out */
+int usdm_allreduce_p2p_import(usdm_p2p* c, int32_t peer, const void* handle64);      /* peer lives in another process */
+int usdm_allreduce_p2p_attach(usdm_p2p* c, int32_t peer, void* peer_local_base);     /* peer lives in this process */
+void* usdm_allreduce_p2p_base(const usdm_p2p* c);                                    /* this rank's buffer */
+int usdm_allreduce_p2p_commit(usdm_p2p* c, usdm_stream_t stream);                    /* all peers known: publish the device view */
+const usdm_p2p_dev* usdm_allreduce_p2p_dev(const usdm_p2p* c);                       /* device pointer for kernel args */
+int usdm_allreduce_p2p_error(const usdm_p2p* c, int32_t* host_err, int32_t* host_epoch);  /* synchronous 8-byte read */
+int usdm_allreduce_p2p_destroy(usdm_p2p* c);
+/* split mode, second half (and the validation form): h[n] = bf16(h[n] + bf16(sum_r slot[site][r][n])), n < n_elems */
+int usdm_allreduce_p2p_reduce(const usdm_p2p_dev* dev, int32_t site, int32_t n_elems, void* h_bf16, const int32_t* skip,
+                              usdm_stream_t stream);
+/* Vocab-parallel token pick: arg-max over this rank's lm_head partials, the (value, id) pair exchanged with every rank
+ * through `site`, global arg-max (ties -> lowest id) identical on every rank, decode state advanced as
+ * usdm_argmax_final does, epoch += 1.  One launch replaces all_gather x2 + usdm_argmax_final.
+ * phase 0: put + get in one launch; phase 1 / 2: the put half / the get half as separate launches (split form). */
+int usdm_argmax_p2p(const float* part_val, const int32_t* part_idx, int32_t nparts, const usdm_decode_state* st,
+                    const usdm_p2p_dev* dev, int32_t site, int32_t phase, const void* embed_table_bf16, int32_t Hd,
+                    void* h_out_bf16, usdm_stream_t stream);
 
 /* h = bf16(h + bf16(delta)) : residual add after a tensor-parallel all-reduce of f32 partial sums */
 int usdm_residual_add(void* h_bf16, const float* delta, int32_t n, usdm_stream_t stream);

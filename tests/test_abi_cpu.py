@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from usdm_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "usdm_hip.h")).read()
-    names = set(re.findall(r"^(?:int|const char\*)\s+(usdm_\w+)\s*\(", hdr, flags=re.M))
-    assert len(names) >= 20, names
+    names = set(re.findall(r"^(?:int|int64_t|void\*|const char\*|const usdm_p2p_dev\*)\s+(usdm_\w+)\s*\(", hdr, flags=re.M))
+    assert len(names) >= 40 and "usdm_allreduce_p2p_create" in names and "usdm_allreduce_p2p_bytes" in names, names
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
@@ -57,3 +57,15 @@ def test_inference_helpers_match_reference_semantics():
     from oracle.units_oracle import banned_ranges
     ids = {w[0] for w in b}
     assert ids == {i for lo, hi in banned_ranges("text2unit") for i in range(lo, hi)}
+
+
+def test_p2p_buffer_layout_arithmetic():
+    """usdm_allreduce_p2p_*: one rank's exchange buffer = 256-byte header + [parity 2][site][src 8][elem] 8-byte granules;
+    the 7B decode needs 2*32+1 sites of 4096 elements = 34 MB per rank."""
+    from usdm_amd import p2p
+    assert p2p.lib.usdm_allreduce_p2p_bytes(ctypes.c_int32(65), ctypes.c_int32(4096)) == 256 + 2 * 65 * 8 * 4096 * 8
+    assert p2p.lib.usdm_allreduce_p2p_bytes(ctypes.c_int32(1), ctypes.c_int32(2)) == 256 + 2 * 8 * 2 * 8
+    # no GPU here: creating a communicator must fail with an error code and a message, not crash
+    h = ctypes.c_void_p()
+    rc = p2p.lib.usdm_allreduce_p2p_create(ctypes.c_int32(0), ctypes.c_int32(9), ctypes.c_int32(1), ctypes.c_int32(2), ctypes.c_int32(10), ctypes.byref(h))
+    assert rc == 2 and b"world" in p2p.lib.usdm_last_error()

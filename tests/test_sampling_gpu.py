@@ -86,3 +86,33 @@ def test_generate_sampling(dev):
     g1 = m.generate(top_k=1, **kw)
     g2 = m.generate(input_ids=ids, max_new_tokens=24, do_sample=False, bad_words_ids=bad)
     assert torch.equal(g1, g2)
+    # one captured decode graph / prefill plan serves every (temperature, top-k, top-p, seed): the knobs live in device memory
+    assert len(m._decodes) == 2 and sum(1 for k in m._prefill_plans if k[2]) == 1
+    # default seed: drawn from torch's global generator -> calls differ, reproducible under manual_seed (HF sampling behaviour)
+    torch.manual_seed(1234); d1 = m.generate(top_k=50, **kw)
+    d2 = m.generate(top_k=50, **kw)
+    torch.manual_seed(1234); d3 = m.generate(top_k=50, **kw)
+    assert torch.equal(d1, d3) and not torch.equal(d1, d2)
+
+
+def test_sample_all_banned_or_nan_never_leaves_the_vocabulary(dev):
+    """with zero kept mass (every logit -inf, or NaN) the kernel used to emit id_offset-1 and read the embedding
+    table out of range.  Now: arg-max of the finite logits, else id 0."""
+    from usdm_amd import ops
+    V = 777
+    E = torch.randn(V, 64, device=dev).to(torch.bfloat16)
+    h = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+    nxt, outt, step, pos = (torch.zeros(n, dtype=torch.int32, device=dev) for n in (1, 8, 1, 1))
+    for fill, expect in ((float("-inf"), 0), (float("nan"), 0)):
+        x = torch.full((V,), fill, device=dev)
+        st = ops.decode_state(nxt, outt, step, pos)
+        step.zero_()
+        ops.sample_final(x, st, temperature=1.0, top_k=0, top_p=0.9, seed=3, embed=E, h_out=h, Hd=64)
+        torch.cuda.synchronize()
+        assert int(nxt.item()) == expect and torch.equal(h, E[expect])
+    x = torch.full((V,), float("nan"), device=dev)
+    x[123] = -5.0                                   # a single finite logit among NaNs: mass is NaN -> falls back to the arg-max
+    st = ops.decode_state(nxt, outt, step, pos)
+    ops.sample_final(x, st, temperature=1.0, top_k=0, top_p=1.0, seed=3, embed=E, h_out=h, Hd=64)
+    torch.cuda.synchronize()
+    assert 0 <= int(nxt.item()) < V

@@ -109,6 +109,7 @@ class GemvArgs(C.Structure):
         ("residual", C.c_void_p), ("y16", C.c_void_p), ("y32", C.c_void_p),
         ("ban", C.c_void_p), ("part_val", C.c_void_p), ("part_idx", C.c_void_p), ("idx_offset", C.c_int32),
         ("x_delta", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p),
+        ("p2p", C.c_void_p), ("p2p_site", C.c_int32), ("p2p_mode", C.c_int32),
     ]
 
 
@@ -126,10 +127,19 @@ class DecodeState(C.Structure):
     ]
 
 
+class P2pDev(C.Structure):
+    _fields_ = [("base", C.c_uint64 * 8), ("rank", C.c_int32), ("world", C.c_int32), ("n_sites", C.c_int32), ("max_elems", C.c_int32),
+                ("timeout_ticks", C.c_uint64)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
 class SampleArgs(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p), ("V", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
-        ("seed", C.c_uint64), ("probs_out", C.c_void_p),
+        ("seed", C.c_uint64), ("probs_out", C.c_void_p), ("dev_params", C.c_void_p),
     ]
 
 
@@ -166,8 +176,8 @@ def _selfcheck():
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
                       ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs),
-                      ("gemv_batch", GemvBatchArgs)):
-        n = getattr(lib, f"usdm_sizeof_{name}" if name == "decode_state" else f"usdm_sizeof_{name}_args")()
+                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev)):
+        n = getattr(lib, f"usdm_sizeof_{name}" if name in ("decode_state", "p2p_dev") else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")
 

@@ -9,6 +9,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/usdm_hip.h"
+#include "p2p.h"
 
 #ifndef USDM_UNR1
 #define USDM_UNR1 8   // ring depth of the one-row-per-wave variants (o_proj / down_proj)
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   __shared__ int si[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int skipv = a.skip ? *a.skip : 0;   // requested now, tested once the first ring is in flight (no exposed latency)
+  const unsigned p2p_epoch = a.p2p_mode ? p2p_load_epoch(a.p2p) : 0u;      // likewise: used only in the epilogue
+  const bool p2p_failed = a.p2p_mode ? p2p_load_err(a.p2p) != 0u : false;
   GTR(0);
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
@@ -210,6 +213,45 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
         if (sv[w] > bv) { bv = sv[w]; bi = si[w]; }
       a.part_val[blockIdx.x] = bv;
       a.part_idx[blockIdx.x] = bi == 0x7fffffff ? bi : bi + a.idx_offset;
+    }
+    return;
+  }
+  if (!GLU && a.p2p_mode) {
+    // Row-parallel projection of the tensor-parallel decode: the all-reduce of the f32 partial sums happens HERE, between the
+    // workgroups that own the same rows on every rank (protocol: include/usdm_hip.h, usdm_allreduce_p2p_*).  No workgroup
+    // waits for another workgroup of its own rank, so progress never depends on how much of the grid is resident.
+    const usdm_p2p_dev* d = a.p2p;
+    constexpr int RPB = NWV * RW;
+    float* prow = (float*)smem;          // [RPB] this rank's partials (x in LDS is dead after the K loop)
+    float* pg = prow + RPB;              // [world][RPB] gathered partials
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) prow[wave * RW + j] = acc[j];
+    }
+    __syncthreads();
+    const int wb = blockIdx.x * RPB, world = d->world, me = d->rank;
+    for (int t = tid; t < world * RPB; t += NTH) {          // put: one granule per (peer, row), coalesced per peer
+      const int peer = t / RPB, r = t - peer * RPB;
+      if (wb + r < a.N) p2p_put(p2p_slot(d, peer, p2p_epoch, a.p2p_site, me) + wb + r, p2p_epoch, prow[r]);
+    }
+    if (a.p2p_mode == 2) return;                            // split mode: usdm_allreduce_p2p_reduce finishes
+    for (int t0 = 0; t0 < world * RPB; t0 += NTH) {         // get: uniform trip count (p2p_get is a wave-uniform bounded loop)
+      const int t = t0 + tid;
+      const int src = t / RPB, r = t - src * RPB;
+      const bool in = t < world * RPB;
+      const bool want = in && wb + r < a.N && src != me;
+      const float v = p2p_get(d, p2p_slot(d, me, p2p_epoch, a.p2p_site, want ? src : 0) + (want ? wb + r : 0), p2p_epoch, want,
+                              USDM_P2P_ERR_TIMEOUT_ROWS, p2p_failed);
+      if (in) pg[src * RPB + r] = (src == me) ? prow[r] : v;
+    }
+    __syncthreads();
+    if (tid < RPB && wb + tid < a.N) {
+      const int n = wb + tid;
+      float s = 0.f;
+      for (int src = 0; src < world; ++src) s += pg[src * RPB + tid];   // fixed rank order: identical bits on every rank
+      const float v = round_bf(round_bf(s) + bf2f(((const bf16_t*)a.residual)[n]));
+      ((bf16_t*)a.y16)[n] = f2bf(v);
     }
     return;
   }
@@ -790,6 +832,10 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(!a.part_val || (a.part_idx && !glu), "usdm_gemv: part_idx missing / lm_head mode is not GLU");
   USDM_CHECK_ARG(!a.norm_w || a.K % 8 == 0, "usdm_gemv: K");
   USDM_CHECK_ARG(!a.x_out || (a.x_delta && a.x_out != a.x), "usdm_gemv: x_out needs x_delta and must not alias x");
+  USDM_CHECK_ARG(a.p2p_mode >= 0 && a.p2p_mode <= 2, "usdm_gemv: p2p_mode");
+  USDM_CHECK_ARG(!a.p2p_mode || (a.p2p && a.p2p_site >= 0 && a.act == USDM_ACT_NONE && !a.part_val && a.residual && a.y16),
+                 "usdm_gemv: the fused all-reduce needs a plain row-parallel projection with residual + y16");
+  // (its LDS scratch, 9 x rows-per-workgroup floats <= 864 B, reuses the x staging area: Kpad * 2 >= 1024 B always)
   const int nout = glu ? a.N / 2 : a.N;
   const int Kpad = (a.K + 511) & ~511;
   hipStream_t st = (hipStream_t)stream;

@@ -48,7 +48,7 @@ __device__ float block_max(float v, float* sred) {
   return m;
 }
 
-__global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args a, usdm_decode_state st, const bf16_t* E, int Hd,
+__global__ __launch_bounds__(NT) void sample_final_kernel(usdm_sample_args a, usdm_decode_state st, const bf16_t* E, int Hd,
                                                            bf16_t* h_out) {
   __shared__ unsigned long long hist[256];
   __shared__ unsigned long long sscan[NT];
@@ -58,6 +58,12 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
   __shared__ int s_tok;
   const int tid = threadIdx.x, V = a.V;
   if (st.done && *st.done) return;
+  if (a.dev_params) {   // per-request knobs live in device memory: one captured graph for every request
+    a.temperature = a.dev_params->temperature; a.top_k = a.dev_params->top_k; a.top_p = a.dev_params->top_p; a.seed = a.dev_params->seed;
+    if (!(a.temperature > 0.f)) a.temperature = 1.0f;
+    if (!(a.top_p > 0.f) || a.top_p > 1.0f) a.top_p = 1.0f;
+    if (a.top_k < 0) a.top_k = 0;
+  }
   const float invT = 1.0f / a.temperature;   // HF divides; x / T and x * (1 / T) differ by <= 1 ulp, below the logits' bf16 grain
   auto X = [&](int i) { return a.logits[i] * invT; };
 
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
   const int step = *st.step;
   const double u = philox_uniform(a.seed, (unsigned)step);
   unsigned long long target = (unsigned long long)(u * (double)Zk);
-  if (target >= Zk) target = Zk - 1;
+  if (Zk > 0 && target >= Zk) target = Zk - 1;
   const unsigned long long excl = sscan[tid] - loc;
   if (tid == 0) s_tok = -1;
   __syncthreads();
@@ -183,6 +189,29 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
     s_tok = pick;
   }
   __syncthreads();
+  if (s_tok < 0) {   // no id has positive mass (all banned / NaN logits): arg-max of the finite logits, else id 0
+    __shared__ float fbv[NT / 64];
+    __shared__ int fbi[NT / 64];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += NT) {
+      const float x = a.logits[i];
+      if (x > bv) { bv = x; bi = i; }     // NaN and -inf never pass
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { fbv[tid >> 6] = bv; fbi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NT / 64; ++w)
+        if (fbv[w] > bv || (fbv[w] == bv && fbi[w] < bi)) { bv = fbv[w]; bi = fbi[w]; }
+      s_tok = bi == 0x7fffffff ? 0 : bi;
+    }
+    __syncthreads();
+  }
   if (a.probs_out) {
     const double inv = Zk > 0 ? 1.0 / (double)Zk : 0.0;
     for (int i = tid; i < V; i += NT) {
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(const usdm_sample_args
 extern "C" int usdm_sample_final(const usdm_sample_args* pa, const usdm_decode_state* st, const void* embed_table, int32_t Hd,
                                  void* h_out, usdm_stream_t stream) {
   USDM_CHECK_ARG(pa && pa->logits && pa->V > 0 && pa->V <= (1 << 20), "usdm_sample_final: logits / V");
-  USDM_CHECK_ARG(pa->temperature > 0.f && pa->top_p > 0.f && pa->top_p <= 1.0f && pa->top_k >= 0,
+  USDM_CHECK_ARG(pa->dev_params || (pa->temperature > 0.f && pa->top_p > 0.f && pa->top_p <= 1.0f && pa->top_k >= 0),
                  "usdm_sample_final: temperature > 0, 0 < top_p <= 1, top_k >= 0 (0 = off)");
   USDM_CHECK_ARG(st && st->next_token && st->out_tokens && st->step && st->pos, "usdm_sample_final: decode state");
   USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_sample_final: embedding output missing");

@@ -8,8 +8,11 @@ Host side: Python plans of C-ABI launches (libusdm_hip.so).
             usdm_attention(mode 1, causal GQA)                                   — one eager plan per prompt length
   decode  : usdm_gemv x4 per layer (RMSNorm, residual add, SwiGLU fused), usdm_attn_decode, lm_head GEMV with
             ban-mask + arg-max, all state on the device -> ONE hipGraph replayed per token
-  TP > 1  : Megatron-style shards (q/k/v heads, MLP columns, vocab rows); o_proj/down_proj produce f32 partial
-            sums that are all-reduced over RCCL (torch.distributed 'nccl'), lm_head arg-max partials all-gathered.
+  TP > 1  : Megatron-style shards (q/k/v heads, MLP columns, vocab rows).  Decode: the all-reduce of the o_proj/down_proj
+            partial sums is fused into those GEMVs' epilogues as a one-shot peer-to-peer exchange over xGMI
+            (usdm_amd.p2p.P2PComm; the decode step stays ONE hipGraph with no collective launch), the vocab-parallel token
+            pick likewise (usdm_argmax_p2p).  Prefill (4 MB messages) and the validation path use RCCL through
+            torch.distributed ('nccl'): f32 partial sums all-reduced, arg-max partials all-gathered.
 Weights: HF state-dict key names (model.layers.N.self_attn.q_proj.weight, ...), bf16.
 """
 import math
@@ -72,7 +75,8 @@ def shard_weights(sd_get, cfg, rank, tp, device, dtype=torch.bfloat16):
 
 
 class USDMForCausalLM:
-    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=None, tp_segments=None):
+    def __init__(self, cfg, device, ctx_max=2048, tp_rank=0, tp_size=1, group=None, decode_splits=None, tp_segments=None, p2p=None,
+                 p2p_fused=None):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -84,6 +88,18 @@ class USDMForCausalLM:
         # tp_segments: run the tensor-parallel code path (f32 partial sums + all-reduce + residual-add kernels) even at
         # tp_size 1 — used to exercise that path on a single GPU
         self.tp_path = (tp_size > 1) if tp_segments is None else bool(tp_segments)
+        # p2p: a committed usdm_amd.p2p.P2PComm -> the decode step exchanges its partial sums peer to peer inside the GEMV
+        # epilogues (p2p_fused, default) or through put + usdm_allreduce_p2p_reduce launches (split form, USDM_P2P_FUSED=0)
+        self.p2p = p2p
+        import os as _os
+        self.p2p_fused = (_os.environ.get("USDM_P2P_FUSED", "1") == "1") if p2p_fused is None else bool(p2p_fused)
+        if p2p is not None:
+            if not self.tp_path:
+                raise ValueError("p2p needs the tensor-parallel path (tp_size > 1 or tp_segments=True)")
+            if (p2p.rank, p2p.world) != (tp_rank, tp_size):
+                raise ValueError(f"P2PComm is rank {p2p.rank}/{p2p.world}, the model shard is rank {tp_rank}/{tp_size}")
+            if p2p.n_sites < 2 * c["num_hidden_layers"] + 1 or p2p.max_elems < c["hidden_size"]:
+                raise ValueError("P2PComm too small: needs 2*layers+1 sites of hidden_size elements")
         self.Hq, self.Hkv = c["num_attention_heads"] // tp_size, c["num_key_value_heads"] // tp_size
         if self.Hq * tp_size != c["num_attention_heads"] or self.Hkv * tp_size != c["num_key_value_heads"] or self.Hkv < 1:
             raise ValueError("tp_size must divide both head counts")
@@ -182,6 +198,7 @@ class USDMForCausalLM:
         # device-side end of sequence: st_eos = {count, min_new, ids...}; st_done is set by the token-picking kernel and read by
         # every decode kernel as its skip word, so steps launched past an EOS inside a host chunk return immediately
         self.st_done, self.st_eos = i32(1), i32(8)
+        self.sample_params = ops.sample_params_tensor(dev)   # usdm_sample_params of the current request
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
         self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
@@ -194,21 +211,43 @@ class USDMForCausalLM:
         self.part_idx_loc = ni(self.nparts) if self.tp_path else self.part_idx
 
     # ------------------------------------------------------------------ collectives (TP only)
+    def _host_staged(self):
+        """A gloo group (validation runs with several ranks on ONE GPU, where RCCL refuses to form a group): collectives are
+        staged through host memory.  Never the production transport."""
+        import torch.distributed as dist
+        return dist.get_backend(self.group) == "gloo"
+
     def _all_reduce(self, t):
         import torch.distributed as dist
+        if hasattr(self.group, "usdm_all_reduce"):      # in-process logical ranks (usdm_amd.p2p.InProcessGroup)
+            return self.group.usdm_all_reduce(self.tp_rank, t)
+        if self._host_staged():
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+            return
         dist.all_reduce(t, group=self.group)
 
     def _gather_partials(self):
         import torch.distributed as dist
+        if hasattr(self.group, "usdm_all_gather"):
+            return self.group.usdm_all_gather(self.tp_rank, [self.part_val, self.part_idx], [self.part_val_loc, self.part_idx_loc])
+        if self._host_staged():
+            for dst, src in ((self.part_val, self.part_val_loc), (self.part_idx, self.part_idx_loc)):
+                c = torch.empty(dst.shape, dtype=dst.dtype)
+                dist.all_gather_into_tensor(c, src.cpu(), group=self.group)
+                dst.copy_(c)
+            return
         dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
         dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
 
     def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None, slot=None, skip=None):
         """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
-        sampling=(temperature, top_k, top_p, seed): usdm_sample_final over the ban-masked logits."""
+        sampling=True: usdm_sample_final over the ban-masked logits, knobs read from the device block self.sample_params
+        (written per request by generate(): plans and graphs do not depend on temperature / top-k / top-p / seed)."""
         c = self.cfg
         sl = slot or self   # where the picked token, the decode state and the next input row live (self = the single sequence)
-        want_logits = self.keep_logits or sampling is not None
+        want_logits = self.keep_logits or bool(sampling)
         if want_logits and self.last_logits is None:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
@@ -217,12 +256,26 @@ class USDMForCausalLM:
         single = sl is self
         st = ops.decode_state(sl.st_next, sl.st_out, sl.st_step, sl.st_pos, advance_pos=advance_pos,
                               done=self.st_done if single else None, eos=self.st_eos if single else None)
-        if sampling is not None:
+        if sampling:
             if self.tp_path:
                 raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
-            temperature, top_k, top_p, seed = sampling
-            ops.sample_final(self.last_logits, st, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed,
+            ops.sample_final(self.last_logits, st, dev_params=self.sample_params,
                              embed=self.W["embed"], h_out=self.h_dec, Hd=c["hidden_size"], plan=plan)
+            plan.hold(st)
+            segs.append(plan)
+            return
+        if self.p2p is not None and single:
+            # vocab-parallel pick across ranks in ONE launch (pairs exchanged peer to peer; advances the exchange epoch)
+            kw = dict(embed=self.W["embed"], h_out=sl.h_dec, Hd=c["hidden_size"])
+            site = 2 * c["num_hidden_layers"]
+            if self.p2p_fused:
+                ops.argmax_p2p(sl.part_val_loc, sl.part_idx_loc, self.nparts, st, self.p2p, site, phase=0, plan=plan, **kw)
+            else:       # split form: put | get as two launches with a segment boundary between them
+                ops.argmax_p2p(sl.part_val_loc, sl.part_idx_loc, self.nparts, st, self.p2p, site, phase=1, plan=plan, **kw)
+                plan.hold(st)
+                segs.append(plan)
+                plan = ops.Plan()
+                ops.argmax_p2p(sl.part_val_loc, sl.part_idx_loc, self.nparts, st, self.p2p, site, phase=2, plan=plan, **kw)
             plan.hold(st)
             segs.append(plan)
             return
@@ -289,7 +342,46 @@ class USDMForCausalLM:
         segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
         return segs, io
 
+    def _build_decode_p2p(self):
+        """Tensor-parallel decode step with the all-reduces done peer to peer: the launch sequence of the single-GPU step
+        over this rank's shards; o_proj / down_proj carry the exchange in their epilogues (fused) or are followed by
+        usdm_allreduce_p2p_reduce (split).  Returned as segments cut at every exchange so that a single-process harness can
+        interleave logical ranks; a real rank runs them back to back inside one hipGraph."""
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
+        Hq, Hkv, I = self.Hq, self.Hkv, self.I
+        nq = (Hq + 2 * Hkv) * d
+        segs, plan = [], ops.Plan()
+        Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        h, qkv, ao, act = self.h_dec, Z(nq), Z(Hq * d), Z(I)
+        pm, pl, po = Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS * d, dt=torch.float32)
+        skp, mode = self.st_done, (1 if self.p2p_fused else 2)
+
+        def row_parallel(plan, W, x, K, site):
+            ops.gemv(W, x, N=H, K=K, residual=h, y16=h, skip=skp, p2p=self.p2p, p2p_site=site, p2p_mode=mode, plan=plan)
+            segs.append(plan)
+            plan = ops.Plan()
+            if mode == 2:
+                ops.p2p_reduce(self.p2p, site, H, h, skip=skp, plan=plan)
+            return plan
+
+        for l in range(L):
+            w = self.W["layers"][l]
+            ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
+            ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, plan=plan)
+            plan = row_parallel(plan, w["o"], ao, Hq * d, 2 * l)
+            ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, skip=skp, plan=plan)
+            plan = row_parallel(plan, w["down"], act, I, 2 * l + 1)
+        self._lm_head_and_pick(plan, h, True, segs, None, skip=skp)
+        segs[0].hold(*[t for s_ in segs for t in s_.keep])
+        return segs
+
     def _build_decode(self, sampling=None):
+        if self.p2p is not None:
+            if sampling:
+                raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
+            return self._build_decode_p2p()
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I, tp = self.Hq, self.Hkv, self.I, (2 if self.tp_path else 1)
@@ -495,19 +587,44 @@ class USDMForCausalLM:
         self._ban_cache[key] = (bad_words_ids, t)
         return t
 
+    def _setup_call(self, input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens):
+        """Per-call device state of generate(): prompt ids into the (cached) prefill plan, ban mask, position / step counters,
+        device-side EOS list.  Returns (prefill segments, the EOS ids the device checks)."""
+        L0 = input_ids.shape[1]
+        key = (L0 - past, past, sampling)
+        if key not in self._prefill_plans:
+            if len(self._prefill_plans) >= 24:
+                self._prefill_plans.pop(next(iter(self._prefill_plans)))
+            self._prefill_plans[key] = self._build_prefill(L0 - past, sampling, past=past)
+        segs, io = self._prefill_plans[key]
+        io["ids"].copy_(input_ids[0, past:])
+        self._kv_ids, self._vt_upto = None, L0      # (set again once this call's decode steps are known)
+        self.ban.copy_(self._ban_mask(bad_words_ids))
+        self.st_pos.fill_(L0)
+        self.st_step.zero_()
+        eos_list = sorted(set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])) if eos_token_id is not None else []
+        dev_eos = eos_list if len(eos_list) <= 6 else []      # more ids than the device list holds: host-side check only
+        self.st_eos.copy_(torch.tensor(([len(dev_eos), int(min_new_tokens)] + dev_eos + [0] * 6)[:8], dtype=torch.int32))
+        self.st_done.zero_()
+        return segs, dev_eos
+
     @torch.no_grad()
     def generate(self, input_ids=None, max_length=None, do_sample=False, bad_words_ids=None, top_p=1.0, top_k=None,
-                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, seed=0, **unused):
+                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, seed=None, **unused):
         """Generation with the call shape of src/inference.py:63-83.  Greedy when do_sample is False or top_k == 1 (what the
         reference passes: arg-max of the ban-masked logits).  Otherwise temperature / top-k / top-p sampling on the device
-        (usdm_sample_final; `seed` keys its Philox stream — torch's global generator is not consulted)."""
+        (usdm_sample_final).  `seed` keys its Philox stream; seed=None draws a fresh one from torch's global CPU generator,
+        so calls differ from each other as HF sampling does and are reproducible under torch.manual_seed."""
         if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
             raise ValueError("input_ids must be a LongTensor of shape [1, L] (batch 1, as the reference calls it)")
-        sampling = None
+        sampling = False
         if do_sample and top_k != 1:
             if not (temperature > 0) or not (0 < top_p <= 1):
                 raise ValueError("temperature must be > 0 and top_p in (0, 1]")
-            sampling = (float(temperature), int(top_k or 0), float(top_p), int(seed))
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            sampling = True
+            ops.set_sample_params(self.sample_params, temperature, int(top_k or 0), top_p, seed)
         elif temperature != 1.0 or top_p != 1.0:
             if not do_sample:
                 raise ValueError("temperature / top_p only apply with do_sample=True")
@@ -532,24 +649,16 @@ class USDMForCausalLM:
             if past > self._vt_upto:   # K/V appended by decode steps have no V^T yet: one transposed copy over all layers
                 a0 = self._vt_upto
                 self.vtc[:, :, :, a0:past] = self.vcache[:, :, a0:past, :].transpose(2, 3)
-        key = (L0 - past, past, sampling)
-        if key not in self._prefill_plans:
-            if len(self._prefill_plans) >= 24:
-                self._prefill_plans.pop(next(iter(self._prefill_plans)))
-            self._prefill_plans[key] = self._build_prefill(L0 - past, sampling, past=past)
-        segs, io = self._prefill_plans[key]
-        io["ids"].copy_(input_ids[0, past:])
-        self._kv_ids, self._vt_upto = None, L0      # (set again once this call's decode steps are known)
-        self.ban.copy_(self._ban_mask(bad_words_ids))
-        self.st_pos.fill_(L0)
-        self.st_step.zero_()
-        eos_list = sorted(set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])) if eos_token_id is not None else []
-        dev_eos = eos_list if len(eos_list) <= 6 else []      # more ids than the device list holds: host-side check only
-        self.st_eos.copy_(torch.tensor(([len(dev_eos), int(min_new_tokens)] + dev_eos + [0] * 6)[:8], dtype=torch.int32))
-        self.st_done.zero_()
+        segs, dev_eos = self._setup_call(input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens)
         self._run_segs(segs)  # prefill + first token
         if sampling not in self._decodes:
             dsegs = self._build_decode(sampling)
+            if self.p2p is not None:      # kernels only (the exchange lives inside them): one plan, one hipGraph
+                merged = ops.Plan()
+                for s_ in dsegs:
+                    merged.calls += s_.calls
+                    merged.hold(*s_.keep)
+                dsegs = [merged]
             self._decodes[sampling] = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
         self._decode = self._decodes[sampling]
         eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
@@ -559,6 +668,8 @@ class USDMForCausalLM:
             n_dev = int(self.st_step.item()) if dev_eos else produced   # steps past a device-side EOS did not run
             produced = min(produced, n_dev)
             toks = self.st_out[:produced].tolist()  # host sync point (EOS check)
+            if self.p2p is not None:
+                self.p2p.raise_if_failed()          # a peer that never delivered surfaces here, not as a hang
             hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
             if hit:
                 toks = toks[:hit[0] + 1]

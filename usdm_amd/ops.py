@@ -208,8 +208,9 @@ def process_unit(units, rep, hop):
 
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
-         ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, plan=None):
-    """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h)."""
+         ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, p2p=None, p2p_site=0,
+         p2p_mode=0, plan=None):
+    """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h).  p2p: a usdm_amd.p2p.P2PComm (fused all-reduce)."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out, skip)
     if x_out is not None and x_out.data_ptr() == x.data_ptr():
         raise ValueError("usdm_gemv: x_out must not alias x")
@@ -220,7 +221,26 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
     a.x_delta, a.x_out, a.skip = _ptr(x_delta), _ptr(x_out), _ptr(skip)
+    if p2p is not None and p2p_mode:
+        p2p.check_site(p2p_site, N)
+        a.p2p, a.p2p_site, a.p2p_mode = p2p.dev_ptr, p2p_site, p2p_mode
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
+
+
+def p2p_reduce(p2p, site, n, h, skip=None, plan=None):
+    """usdm_allreduce_p2p_reduce: second half of the split form: h = bf16(h + bf16(sum over ranks of slot[site]))."""
+    _need_cuda(h, skip)
+    p2p.check_site(site, n)
+    _go(plan, "usdm_allreduce_p2p_reduce", lib.usdm_allreduce_p2p_reduce, C_.c_void_p(p2p.dev_ptr), C_.c_int32(site), C_.c_int32(n),
+        _ptr(h), _ptr(skip))
+
+
+def argmax_p2p(part_val, part_idx, nparts, st, p2p, site, phase=0, embed=None, h_out=None, Hd=0, plan=None):
+    """usdm_argmax_p2p: vocab-parallel token pick across ranks + decode-state update + epoch advance."""
+    _need_cuda(part_val, part_idx, embed, h_out)
+    p2p.check_site(site, 2)
+    _go(plan, "usdm_argmax_p2p", lib.usdm_argmax_p2p, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st),
+        C_.c_void_p(p2p.dev_ptr), C_.c_int32(site), C_.c_int32(phase), _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 
 def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=True, batch=0, done=None, eos=None):
@@ -240,12 +260,24 @@ def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, p
         _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 
-def sample_final(logits, st, *, temperature=1.0, top_k=0, top_p=1.0, seed=0, probs_out=None, embed=None, h_out=None, Hd=0, plan=None):
-    """usdm_sample_final: temperature / top-k / top-p sampling of one token from ban-masked f32 logits."""
-    _need_cuda(logits, probs_out, embed, h_out)
+def sample_params_tensor(device):
+    """24-byte device block holding one usdm_sample_params (temperature, top_k, top_p, reserved, seed)."""
+    return torch.zeros(C.sizeof(_lib.SampleParams), dtype=torch.uint8, device=device)
+
+
+def set_sample_params(t, temperature, top_k, top_p, seed):
+    p = _lib.SampleParams(float(temperature), int(top_k), float(top_p), 0, int(seed) & 0xFFFFFFFFFFFFFFFF)
+    t.copy_(torch.frombuffer(bytearray(bytes(p)), dtype=torch.uint8))
+
+
+def sample_final(logits, st, *, temperature=1.0, top_k=0, top_p=1.0, seed=0, probs_out=None, embed=None, h_out=None, Hd=0,
+                 dev_params=None, plan=None):
+    """usdm_sample_final: temperature / top-k / top-p sampling of one token from ban-masked f32 logits.
+    dev_params (sample_params_tensor): the knobs are read from device memory instead (graph-replayable per request)."""
+    _need_cuda(logits, probs_out, embed, h_out, dev_params)
     a = SampleArgs()
     a.logits, a.V, a.temperature, a.top_k, a.top_p = _ptr(logits), logits.numel(), temperature, top_k, top_p
-    a.seed, a.probs_out = seed, _ptr(probs_out)
+    a.seed, a.probs_out, a.dev_params = seed, _ptr(probs_out), _ptr(dev_params)
     _go(plan, "usdm_sample_final", lib.usdm_sample_final, C_.byref(a), C_.byref(st), _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 

@@ -1,0 +1,171 @@
+"""Host side of the one-shot peer-to-peer all-reduce (C-ABI: usdm_allreduce_p2p_*, include/usdm_hip.h).
+
+P2PComm owns this rank's uncached exchange buffer and the mappings of every peer's buffer:
+  * ranks in different processes (the production form, one process per GPU): the 64-byte hipIpc handles travel over any
+    host channel - here torch.distributed.all_gather_object on the job's process group (gloo or nccl);
+  * logical ranks inside one process (single-GPU validation): buffers are attached by address.
+"""
+import ctypes as C
+import os
+
+from ._lib import check, lib
+
+lib.usdm_allreduce_p2p_bytes.restype = C.c_int64
+lib.usdm_allreduce_p2p_base.restype = C.c_void_p
+lib.usdm_allreduce_p2p_dev.restype = C.c_void_p
+
+HANDLE_BYTES = 64
+MAX_RANKS = 8
+
+
+class P2PError(RuntimeError):
+    pass
+
+
+class P2PComm:
+    def __init__(self, rank, world, n_sites, max_elems, timeout_ms=None):
+        if timeout_ms is None:
+            timeout_ms = int(os.environ.get("USDM_P2P_TIMEOUT_MS", "10000"))
+        self.rank, self.world, self.n_sites, self.max_elems = rank, world, n_sites, max_elems
+        self._h = C.c_void_p()
+        check(lib.usdm_allreduce_p2p_create(C.c_int32(rank), C.c_int32(world), C.c_int32(n_sites), C.c_int32(max_elems),
+                                            C.c_int32(timeout_ms), C.byref(self._h)), "usdm_allreduce_p2p_create")
+        self.dev_ptr = None
+        self.base = lib.usdm_allreduce_p2p_base(self._h)
+        self.nbytes = lib.usdm_allreduce_p2p_bytes(C.c_int32(n_sites), C.c_int32(max_elems))
+
+    # ---- wiring
+    def export_handle(self):
+        buf = (C.c_char * HANDLE_BYTES)()
+        check(lib.usdm_allreduce_p2p_export(self._h, buf), "usdm_allreduce_p2p_export")
+        return bytes(buf)
+
+    def import_handle(self, peer, handle):
+        check(lib.usdm_allreduce_p2p_import(self._h, C.c_int32(peer), C.c_char_p(handle)), "usdm_allreduce_p2p_import")
+
+    def attach(self, peer, other):
+        check(lib.usdm_allreduce_p2p_attach(self._h, C.c_int32(peer), C.c_void_p(other.base)), "usdm_allreduce_p2p_attach")
+
+    def commit(self):
+        check(lib.usdm_allreduce_p2p_commit(self._h, C.c_void_p(0)), "usdm_allreduce_p2p_commit")
+        self.dev_ptr = lib.usdm_allreduce_p2p_dev(self._h)
+        if not self.dev_ptr:
+            raise P2PError("usdm_allreduce_p2p_commit left no device view")
+
+    @classmethod
+    def from_process_group(cls, group, n_sites, max_elems, timeout_ms=None):
+        """One rank per process: exchange the hipIpc handles over `group` and map every peer."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        c = cls(rank, world, n_sites, max_elems, timeout_ms)
+        handles = [None] * world
+        dist.all_gather_object(handles, c.export_handle(), group=group)
+        for r in range(world):
+            if r != rank:
+                c.import_handle(r, handles[r])
+        c.commit()
+        dist.barrier(group=group)      # every rank has mapped every buffer before anybody writes
+        return c
+
+    @classmethod
+    def in_process(cls, world, n_sites, max_elems, timeout_ms=None):
+        """`world` logical ranks inside this process (one GPU): the single-GPU validation form."""
+        comms = [cls(r, world, n_sites, max_elems, timeout_ms) for r in range(world)]
+        for a in comms:
+            for b in comms:
+                if a is not b:
+                    a.attach(b.rank, b)
+            a.commit()
+        return comms
+
+    # ---- use
+    def check_site(self, site, n):
+        if self.dev_ptr is None:
+            raise P2PError("P2PComm is not committed")
+        if not (0 <= site < self.n_sites) or n > self.max_elems:
+            raise ValueError(f"p2p site {site} / {n} elements outside the communicator ({self.n_sites} sites x {self.max_elems})")
+
+    def status(self):
+        """(err, epoch): synchronous 8-byte read of this rank's header."""
+        err, ep = C.c_int32(0), C.c_int32(0)
+        check(lib.usdm_allreduce_p2p_error(self._h, C.byref(err), C.byref(ep)), "usdm_allreduce_p2p_error")
+        return err.value, ep.value
+
+    def raise_if_failed(self):
+        err, ep = self.status()
+        if err:
+            raise P2PError(f"peer-to-peer all-reduce timed out on rank {self.rank} (error word {err:#x}, epoch {ep}): a peer never "
+                           f"delivered its partial sums within the bound; results from this point on are invalid")
+
+    def close(self):
+        if self._h:
+            lib.usdm_allreduce_p2p_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class InProcessGroup:
+    """Collectives between LOGICAL ranks that live in one process on one GPU (validation of the tensor-parallel algebra and
+    of the peer-to-peer exchange without a multi-GPU node).  Two flavours:
+      threaded=False  ranks are driven one after another by a lockstep harness (tests/_tp_lockstep.py): a collective completes
+                      when the LAST rank has called it (calls must come in rank order);
+      threaded=True   every rank runs generate() in its own thread on its own stream: a collective is a thread barrier.
+    The prefill all-reduces and the RCCL-path gathers go through here; the decode exchange does not (it is in the kernels)."""
+
+    def __init__(self, world, threaded=False):
+        import threading
+        self.world, self.threaded = world, threaded
+        self._pend = []
+        self._bar = threading.Barrier(world) if threaded else None
+        self._slots = [None] * world
+
+    def _sum_into_all(self, tensors):
+        import torch
+        torch.cuda.synchronize()
+        acc = tensors[0].clone()
+        for t in tensors[1:]:
+            acc += t                      # rank order
+        for t in tensors:
+            t.copy_(acc)
+        torch.cuda.synchronize()
+
+    def usdm_all_reduce(self, rank, t):
+        if self.threaded:
+            self._slots[rank] = t
+            if self._bar.wait() == 0:
+                self._sum_into_all(list(self._slots))
+            self._bar.wait()
+            return
+        assert rank == len(self._pend), "lockstep collectives must be called in rank order"
+        self._pend.append(t)
+        if len(self._pend) == self.world:
+            self._sum_into_all(self._pend)
+            self._pend = []
+
+    def usdm_all_gather(self, rank, dsts, srcs):
+        """dsts[i] <- concatenation over ranks of srcs[i] (lists: one rendezvous for several tensors)."""
+        import torch
+
+        def finish(entries):
+            torch.cuda.synchronize()
+            for i in range(len(entries[0][0])):
+                cat = torch.cat([e[1][i] for e in entries])
+                for e in entries:
+                    e[0][i].copy_(cat)
+            torch.cuda.synchronize()
+        if self.threaded:
+            self._slots[rank] = (dsts, srcs)
+            if self._bar.wait() == 0:
+                finish(list(self._slots))
+            self._bar.wait()
+            return
+        assert rank == len(self._pend), "lockstep collectives must be called in rank order"
+        self._pend.append((dsts, srcs))
+        if len(self._pend) == self.world:
+            finish(self._pend)
+            self._pend = []
