@@ -53,8 +53,32 @@ class Pipeline:
         self.dev, self.rank, self.world, self.args = dev, rank, world, args
         t0 = time.time()
         self.ue = synth.make_unit_extractor(dev)
+        # Tensor-parallel decode transport: one-shot peer-to-peer exchange fused into the GEMV epilogues (default), RCCL
+        # through torch.distributed as the fallback.  The transport is CHECKED on the real ranks before it is trusted
+        # (usdm_amd.p2p.self_test): if the check fails on this node the bench falls back to RCCL and says so in its JSON line.
+        self.tp_comm, comm = "none", None
+        if world > 1 or args.force_dist:
+            self.tp_comm = "rccl"
+            if os.environ.get("USDM_TP_COMM", "p2p") == "p2p":
+                import torch.distributed as dist
+                from usdm_amd.llm import MISTRAL_7B_USDM as C7
+                from usdm_amd.p2p import P2PComm, self_test
+                why = None
+                try:
+                    probe = P2PComm.from_process_group(group, 3, 1024, timeout_ms=3000)
+                    why = self_test(probe, group, dev)
+                    probe.close()
+                except Exception as e:  # noqa: BLE001
+                    why = repr(e)
+                flag = torch.tensor([0 if why is None else 1], device=dev)
+                dist.all_reduce(flag, group=group)          # every rank must take the same decision
+                if int(flag.item()) == 0:
+                    comm = P2PComm.from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
+                    self.tp_comm = "p2p (one-shot xGMI exchange fused into the row-parallel GEMV epilogues; self-test passed)"
+                else:
+                    self.tp_comm = f"rccl (p2p self-test failed on {int(flag.item())} rank(s): {why})"
         self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group,
-                                  tp_segments=True if (args.force_dist or world > 1) else None)
+                                  tp_segments=True if (args.force_dist or world > 1) else None, p2p=comm)
         self.vb = synth.make_voicebox(dev)
         self.voc = synth.make_bigvgan(dev, compute_dtype=torch.float32 if args.vocoder_dtype == "f32" else torch.bfloat16)
         torch.cuda.synchronize()
@@ -374,7 +398,7 @@ def main():
                                "Token-Voicebox 63 NFE (Heun, CFG, 3 s prompt) -> BigVGAN",
                    "wave_samples": 160000, "prompt_tokens": list(pipe.prompt_lens), "generated_tokens": pipe.n_generated,
                    "voicebox_n_timesteps": args.nt, "mel_frames": pipe.frames, "output_samples": int(audio.shape[0]),
-                   "parallelism": f"tp{world} (LLM) + replicas"},
+                   "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm},
         "llm_tokens_per_s": round(pipe.n_generated / (llm_ms * 1e-3), 2),
         "llm_decode_tokens_per_s_tts_round": round(args.units / (stages["llm_tts"] * 1e-3), 2),
         "stage_ms": {k: round(v, 2) for k, v in stages.items()},

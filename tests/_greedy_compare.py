@@ -31,8 +31,10 @@ def compare_greedy(model, dev, ids, ref, ref_logits, new, max_restarts=8, **gen_
         gap = (top2[0] - top2[1]).item()
         assert gap <= NEAR_TIE_REL * top2[0].abs().item() + NEAR_TIE_ABS, \
             f"generated token {j}: HIP {gen[first]} vs oracle {ref_gen[j]} with oracle top-2 gap {gap} (not a near-tie)"
-        # the HIP choice must be the oracle's runner-up (the other side of the tie)
-        assert gen[first] == int(torch.topk(ref_logits[j], 2).indices[1]), f"token {j}: HIP picked neither of the oracle's top 2"
+        # the HIP choice must itself lie inside the oracle's near-tie band (ties can be more than two-way)
+        mine = ref_logits[j][gen[first]].item()
+        assert top2[0].item() - mine <= NEAR_TIE_REL * top2[0].abs().item() + NEAR_TIE_ABS, \
+            f"token {j}: HIP picked id {gen[first]} whose oracle logit {mine} is outside the near-tie band below {top2[0].item()}"
         div.append(j)
         assert len(div) <= max_restarts, f"too many near-tie divergences: {div}"
         done = j + 1

@@ -26,7 +26,7 @@ def test_config2_tokenizer_10s_full_width_all_35_layers(dev):
     top2 = torch.topk(dist, 2, largest=False).values
     margin = top2[:, 1] - top2[:, 0]
     bad = ids != ref_ids
-    gp, io = ue._plans[(160000, 34)]
+    io = ue.last_io
     ferr = ((io["features"].cpu() - feat).abs().max() / feat.abs().max()).item()
     print(f"config 2: exact ids {(~bad).float().mean().item():.4f}, feature rel err {ferr:.2e}, min top-2 margin {margin.min().item():.3e}")
     assert ferr <= 1e-4

@@ -1,0 +1,67 @@
+"""GPU: a dead hipGraph must never be collected while a stream is capturing (VERDICT r01 #8 / ADVICE r01).
+
+Cause of the round-1 abort, from what is in hand (commit 6c3c371; the log of the failing run was not kept): GraphedPlan objects of
+earlier tests were garbage (each sits in a reference cycle through its plan cache, so only the CYCLIC collector frees them).
+Python's generation-0 collection is triggered by container allocations - Plan.run() makes one argument tuple per launch - so
+it could fire INSIDE `with torch.cuda.graph(g)`.  Collecting a torch.cuda.CUDAGraph runs CUDAGraph::~CUDAGraph -> reset():
+hipGraphExecDestroy / hipGraphDestroy and the release of the graph's private memory pool, i.e. hipFree.  torch captures in
+'global' error mode, where hipFree from any thread is a prohibited call while a capture is open: it invalidates the capture
+and returns an error, and an error thrown from a C++ destructor ends in std::terminate -> the abort that was seen.
+usdm_amd.graph._no_gc() therefore (1) runs a full collection BEFORE the capture opens, so pending garbage is freed legally, and
+(2) keeps the cyclic collector off until the capture is closed.  Nothing inside the captured region drops a tensor or a graph by
+reference count (it is a loop of ctypes calls), so no refcount-driven free can happen there either.
+
+The test builds exactly that situation and checks both halves of the guard; it would abort the process without it."""
+import gc
+import weakref
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dead_graph_in_a_cycle_is_collected_before_capture_and_gc_stays_off_inside(dev):
+    from usdm_amd import ops
+    from usdm_amd.graph import GraphedPlan
+
+    def make(n):
+        a, b = torch.randn(n, device=dev).to(torch.bfloat16), torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        plan = ops.Plan()
+        plan.hold(a, b)
+        ops.copy_bytes(b, a, 2 * n, plan=plan)
+        return plan, a, b
+
+    # 1. a captured graph that becomes garbage inside a reference cycle
+    plan, _, _ = make(4096)
+    dead = GraphedPlan(plan)
+    for _ in range(3):
+        dead.run()
+    assert dead.graph is not None
+    dead.cycle = dead                              # only the cyclic collector can free it now
+    ref = weakref.ref(dead.graph)
+    gc.collect()
+    old = gc.get_threshold()
+    gc.disable()                                   # keep it alive until the capture below...
+    del dead, plan
+    gc.enable()
+    assert ref() is not None
+
+    # 2. capture another plan with the collector set to fire on every container allocation
+    seen = []
+    plan2, a2, b2 = make(8192)
+    plan2.add("probe", lambda st: (seen.append((gc.isenabled(), ref() is None)), 0)[1])    # runs INSIDE the captured region
+    live = GraphedPlan(plan2)
+    gc.set_threshold(1, 1, 1)
+    try:
+        live.run()                                 # eager
+        live.run()                                 # capture (would collect `dead` mid-capture without the guard -> abort)
+    finally:
+        gc.set_threshold(*old)
+    assert live.graph is not None
+    inside = seen[-1]
+    assert inside == (False, True), inside         # collector off inside the capture; the dead graph was already gone
+    assert gc.isenabled()
+    live.run()
+    torch.cuda.synchronize()
+    assert torch.equal(a2, b2)

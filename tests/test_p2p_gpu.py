@@ -125,6 +125,11 @@ def _proc(rank, world, port, q):
         torch.cuda.set_device(dev)
         from usdm_amd.llm import USDMForCausalLM
         from usdm_amd.p2p import P2PComm
+        from usdm_amd.p2p import self_test
+        probe = P2PComm.from_process_group(dist.group.WORLD, 3, 1024)
+        verdict = self_test(probe, dist.group.WORLD, dev)      # the start-up check bench.py runs before trusting the transport
+        assert verdict is None, verdict
+        probe.close()
         comm = P2PComm.from_process_group(dist.group.WORLD, 2 * CFG["num_hidden_layers"] + 1, CFG["hidden_size"])
         m = USDMForCausalLM.from_state_dict(_sd(), CFG, dev, ctx_max=128, tp_rank=rank, tp_size=world, group=dist.group.WORLD, p2p=comm)
         out = m.generate(input_ids=_ids(dev), max_new_tokens=24, bad_words_ids=BAD)[0].tolist()

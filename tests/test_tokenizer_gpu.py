@@ -28,7 +28,7 @@ def _run(dev, cfg, n, layers, out_idx, seed):
     ue = UnitExtractor(None, None, device=dev, config=cfg, state_dict=sd, centroids=cen)
     ids = ue.predict(wave.to(dev), out_idx)
     assert ids.dtype == torch.int64 and ids.shape == ref_ids.shape == (WO.n_frames(wave_o.numel(), cfg),)
-    gp, io = ue._plans[(wave_o.numel(), out_idx)]
+    io = ue.last_io
     ferr = ((io["features"].cpu() - feat).abs().max() / feat.abs().max()).item()
     top2 = torch.topk(dist, 2, largest=False).values
     margin = (top2[:, 1] - top2[:, 0])

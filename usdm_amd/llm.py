@@ -22,6 +22,7 @@ import torch
 from . import ops
 from ._lib import ACT_SWIGLU
 from .graph import GraphedPlan, GraphedSegments
+from .plancache import LRU
 
 MISTRAL_7B_USDM = dict(vocab_size=42003, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                        num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5,
@@ -109,17 +110,24 @@ class USDMForCausalLM:
         V = c["vocab_size"]
         self.Vloc, self.v0, self.v1, self.nparts = vocab_shard(V, tp_rank, tp_size)
         self.ctx_max = (ctx_max + 63) // 64 * 64
+        if self.ctx_max > c.get("sliding_window", 4096):
+            # Mistral-7B-v0.1 attends to the last 4096 positions only (reference: src/model.py:337-341, HF sliding_window);
+            # the kernels here implement full causal attention, which is the same thing up to 4096 tokens and not beyond
+            raise NotImplementedError(f"ctx_max {self.ctx_max} exceeds the sliding window ({c.get('sliding_window', 4096)}): "
+                                      "sliding-window attention is not implemented")
         import os
         # decode attention: 1 = one 16-wave workgroup per kv head (no partials / combine launch); >1 = context split
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", "32")) if decode_splits is None else decode_splits
         if self.NS == 1 and self.ctx_max > 4096:
             self.NS = 16
         self.W = None
-        self._prefill_plans = {}
+        # bounded caches (plancache.LRU): prefill plans are keyed by exact prompt length (a plan is argument structs + ~60 KB of
+        # workspace per token; no hipGraph), decode plans / graphs by {greedy, sampling} only
+        self._prefill_plans = LRU(24)
         self._decode = None
         self._decodes = {}
         self._batches = {}
-        self._ban_cache = {}
+        self._ban_cache = LRU(8)
         self.stats = {}
         self.keep_logits = False  # debug/tests: keep the fp32 (bf16-valued) logits of the last step
         self.last_logits = None
@@ -471,7 +479,7 @@ class USDMForCausalLM:
         bb = dict(kc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
                   vc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
                   nxt=i32(B), step=i32(B), pos=i32(B), out=i32(B, self.max_out), h=torch.zeros(B, H, dtype=bf, device=dev),
-                  pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill={}, decode=None)
+                  pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill=LRU(16), decode=None)
         slots = []
         for b in range(B):
             sl = self._Slot()
@@ -541,9 +549,7 @@ class USDMForCausalLM:
         bb["pos"].copy_(torch.tensor(L0, dtype=torch.int32))
         for b, ids in enumerate(ids_list):            # per-item prefill into that item's cache / state slot (+ first token)
             key = (L0[b], b)
-            if key not in bb["prefill"]:
-                bb["prefill"][key] = self._build_prefill(L0[b], None, slot=bb["slots"][b])
-            segs, io = bb["prefill"][key]
+            segs, io = bb["prefill"].get_or_build(key, lambda: self._build_prefill(L0[b], None, slot=bb["slots"][b]))
             io["ids"].copy_(ids[0])
             self._run_segs(segs)
         if bb["decode"] is None:
@@ -584,7 +590,7 @@ class USDMForCausalLM:
                 raise NotImplementedError("multi-token bad words are not used by the reference path (inference.py:41-45)")
             m[w[0]] = 1
         t = m[self.v0:self.v1].to(self.device).contiguous()
-        self._ban_cache[key] = (bad_words_ids, t)
+        self._ban_cache.put(key, (bad_words_ids, t))
         return t
 
     def _setup_call(self, input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens):
@@ -592,11 +598,7 @@ class USDMForCausalLM:
         device-side EOS list.  Returns (prefill segments, the EOS ids the device checks)."""
         L0 = input_ids.shape[1]
         key = (L0 - past, past, sampling)
-        if key not in self._prefill_plans:
-            if len(self._prefill_plans) >= 24:
-                self._prefill_plans.pop(next(iter(self._prefill_plans)))
-            self._prefill_plans[key] = self._build_prefill(L0 - past, sampling, past=past)
-        segs, io = self._prefill_plans[key]
+        segs, io = self._prefill_plans.get_or_build(key, lambda: self._build_prefill(L0 - past, sampling, past=past))
         io["ids"].copy_(input_ids[0, past:])
         self._kv_ids, self._vt_upto = None, L0      # (set again once this call's decode steps are known)
         self.ban.copy_(self._ban_mask(bad_words_ids))

@@ -169,3 +169,57 @@ class InProcessGroup:
         if len(self._pend) == self.world:
             finish(self._pend)
             self._pend = []
+
+
+def self_test(comm, group, device, rounds=4, N=1024, K=512):
+    """Start-up check of a freshly wired communicator across the REAL ranks of `group`: `rounds` fused all-reduces (the GEMV
+    epilogue form, both parities) checked against the group's own all_reduce of the same f32 partials, and `rounds` cross-rank
+    token picks checked against the known winner.  Returns None if everything matches, else a description of what failed
+    (callers fall back to the RCCL path)."""
+    import torch
+    import torch.distributed as dist
+    from . import ops
+    try:
+        rank, world = comm.rank, comm.world
+        staged = dist.get_backend(group) == "gloo"
+        g = torch.Generator().manual_seed(1000 + rank)
+        gs = torch.Generator().manual_seed(999)          # shared by all ranks
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)
+        for it in range(rounds):
+            W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+            x = torch.randn(K, generator=g).to(torch.bfloat16).to(device)
+            h0 = torch.randn(N, generator=gs).to(torch.bfloat16).to(device)
+            part = torch.zeros(N, dtype=torch.float32, device=device)
+            ops.gemv(W, x, N=N, K=K, round_bf16=False, y32=part)
+            if staged:
+                c = part.cpu(); dist.all_reduce(c, group=group); tot = c.to(device)
+            else:
+                tot = part.clone(); dist.all_reduce(tot, group=group)
+            want = (h0.float() + tot.to(torch.bfloat16).float()).to(torch.bfloat16)
+            h = h0.clone()
+            ops.gemv(W, x, N=N, K=K, residual=h, y16=h, p2p=comm, p2p_site=it % comm.n_sites, p2p_mode=1)
+            torch.cuda.synchronize()
+            err, _ = comm.status()
+            if err:
+                return f"round {it}: exchange timed out (error word {err:#x})"
+            diff = (h.float() - want.float()).abs()
+            ulp = want.float().abs().clamp_min(1e-3) * 2 ** -7
+            if bool((diff > 2 * ulp).any()) or float((diff == 0).float().mean()) < 0.98:
+                return f"round {it}: all-reduce result differs from the group's all_reduce (max diff {float(diff.max()):.3e})"
+            # token pick: rank (it % world) holds the winner
+            pv = torch.full((4,), -1.0 - rank, device=device)
+            pi = torch.arange(4, dtype=torch.int32, device=device) + 100 * rank
+            if rank == it % world:
+                pv[2] = 5.0
+            nxt, out, step, pos = i32(1), i32(8), i32(1), i32(1)
+            st = ops.decode_state(nxt, out, step, pos)
+            ops.argmax_p2p(pv, pi, 4, st, comm, comm.n_sites - 1, phase=0)
+            torch.cuda.synchronize()
+            if int(nxt.item()) != 100 * (it % world) + 2:
+                return f"round {it}: cross-rank token pick returned {int(nxt.item())}"
+        err, ep = comm.status()
+        if err or ep != 1 + rounds:
+            return f"status after self-test: error word {err:#x}, epoch {ep} (expected {1 + rounds})"
+        return None
+    except Exception as e:  # noqa: BLE001 - any failure means: do not use this transport
+        return f"self-test raised {e!r}"

@@ -18,6 +18,11 @@ import torch
 from . import ops
 from ._lib import ACT_GELU
 from .graph import GraphedPlan
+from .plancache import LRU, Arena, bucket
+
+SAMPLE_BUCKET = 16000   # 1 s of 16 kHz audio: lengths inside one bucket share ONE workspace
+MAX_ARENAS = 3          # workspaces kept (least recently used goes first)
+MAX_PLANS = 4           # exact-length plans (+ hipGraphs) kept per workspace
 
 XLSR_1B = dict(conv_dim=(512,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2),
                hidden_size=1280, num_attention_heads=16, intermediate_size=5120, num_hidden_layers=48,
@@ -49,7 +54,8 @@ class UnitExtractor:
                 raise FileNotFoundError(f"{kmeans_uri}: URLs cannot be fetched offline; pass a local .npy or centroids=")
             centroids = torch.from_numpy(np.load(kmeans_uri))
         self._pack(state_dict, centroids)
-        self._plans = {}
+        self._plans = LRU(MAX_ARENAS)     # (sample bucket, layer) -> (Arena, LRU of exact-length plans)
+        self.last_io = None
         self.last_margin = None
 
     # ------------------------------------------------------------------ load-time packing
@@ -99,13 +105,14 @@ class UnitExtractor:
         self.P = P
 
     # ------------------------------------------------------------------ plan
-    def _build(self, n, out_layer_idx):
+    def _build(self, n, out_layer_idx, arena):
         cfg, P, dev = self.cfg, self.P, self.device
         if out_layer_idx >= len(P["layers"]):
             raise ValueError(f"out_layer_idx {out_layer_idx} but only {len(P['layers'])} encoder layers are loaded")
         eps = cfg["layer_norm_eps"]
         plan = ops.Plan()
-        Z = lambda *s, dt=torch.float32: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        arena.begin()
+        Z = lambda *s, dt=torch.float32: arena.zeros(*s, dtype=dt)
         io = dict(wave=Z(n))
         wn = Z(n)
         ops.wave_layernorm(io["wave"], wn, n, eps, plan=plan)
@@ -175,12 +182,21 @@ class UnitExtractor:
         n = x.numel()
         if _frames(n, self.cfg) < 1:
             raise ValueError(f"waveform of {n} samples is shorter than the 400-sample receptive field")
-        key = (n, out_layer_idx)
-        if key not in self._plans:
-            plan, io = self._build(n, out_layer_idx)
-            self._plans[key] = (GraphedPlan(plan), io)
-        gp, io = self._plans[key]
+        nb = bucket(n, SAMPLE_BUCKET)
+
+        def new_arena():
+            a = Arena(self.device)
+            if nb != n:
+                self._build(nb, out_layer_idx, a)          # reserve the workspace at the bucket's capacity
+            return a, LRU(MAX_PLANS)
+        arena, plans = self._plans.get_or_build((nb, out_layer_idx), new_arena)
+
+        def new_plan():
+            plan, io = self._build(n, out_layer_idx, arena)
+            return GraphedPlan(plan), io
+        gp, io = plans.get_or_build(n, new_plan)
+        arena.take(gp)                                       # another length ran on this workspace last -> back to all-zero
         io["wave"].copy_(x)
         gp.run()
-        self.last_margin = io["margin"]
+        self.last_margin, self.last_io = io["margin"], io   # (tests / diagnostics: features, margins of the last call)
         return io["ids"].clone()

@@ -25,6 +25,10 @@ from torch import nn
 from ... import ops
 from ..._lib import ACT_GELU
 from ...graph import GraphedPlan
+from ...plancache import LRU, bucket
+
+FRAME_BUCKET = 32     # rows; one plan + hipGraph + workspace per bucket of utterance lengths
+MAX_PLANS = 6         # per model: least recently used plan (and its ~100 MB workspace at S ~ 1.1 k) is dropped first
 
 
 def get_slopes(n: int):
@@ -107,10 +111,10 @@ class Transformer(nn.Module):
         self.layers = nn.ModuleList([EncoderLayer(hidden_size, intermediate_size, num_attention_heads, attention_dropout, activation_dropout, hidden_dropout) for _ in range(num_hidden_layers)])
         self.skip_connections_layers = nn.ModuleList([nn.Linear(2 * hidden_size, hidden_size) for _ in range(num_hidden_layers // 2)])
         self.proj_out = nn.Conv1d(hidden_size, n_feats, kernel_size=1)
-        self._packed, self._plans = None, {}
+        self._packed, self._plans = None, LRU(MAX_PLANS)
 
     def invalidate(self):
-        self._packed, self._plans = None, {}
+        self._packed, self._plans = None, LRU(MAX_PLANS)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -264,12 +268,20 @@ class Transformer(nn.Module):
             ops.mask_time(vl, B=Bx, T=S1, C=F_, layout=1, off=1, x32=io["out"], plan=plan)
         return plan, io
 
+    @staticmethod
+    def bucket_frames(S1):
+        """Frame count a plan is built for: the token-prefixed length S1 + 1 rounded up to FRAME_BUCKET rows.  Any utterance
+        whose length falls into the bucket runs the SAME plan / hipGraph with its true length in kv_len (the padding masks of
+        networks.py:314-341 that ragged batches use), so results do not depend on the bucket."""
+        return bucket(S1 + 1, FRAME_BUCKET) - 1
+
     def get_plan(self, B_in, S1, dup, use_cond, dev, ragged=False):
         key = (B_in, S1, dup, bool(use_cond), dev.index, bool(ragged))
-        if key not in self._plans:
+
+        def build():
             plan, io = self.build_plan(B_in, S1, dup, use_cond, dev, ragged)
-            self._plans[key] = (GraphedPlan(plan), io)
-        return self._plans[key]
+            return GraphedPlan(plan), io
+        return self._plans.get_or_build(key, build)
 
     @torch.no_grad()
     def forward(self, x, y, cond, t, lengths):
@@ -281,12 +293,15 @@ class Transformer(nn.Module):
         lens = lengths.to("cpu")
         if bool((lens > S1).any()) or bool((lens < 0).any()):
             raise ValueError("lengths must lie in [0, frames]")
-        ragged = not bool((lens == S1).all())
-        gp, io = self.get_plan(B, S1, 1, True, y.device, ragged)
+        Sb = self.bucket_frames(S1)
+        ragged = Sb != S1 or not bool((lens == S1).all())
+        gp, io = self.get_plan(B, Sb, 1, True, y.device, ragged)
         io["kv_len"].copy_((lengths + 1).to(torch.int32))
-        io["ids"].copy_(x)
-        io["y"].copy_(y)
-        io["cond"].copy_(cond)
+        if Sb != S1:
+            io["ids"].zero_(); io["y"].zero_(); io["cond"].zero_()
+        io["ids"][:, :S1].copy_(x)
+        io["y"][:, :, :S1].copy_(y)
+        io["cond"][:, :, :S1].copy_(cond)
         io["t"].copy_(t.reshape(B))
         gp.run()
-        return io["out"].clone()
+        return io["out"][:, :, :S1].clone()

@@ -59,15 +59,23 @@ class CFM(BaseModule):
             if noise.shape != (n_noise, B, F_, S):
                 raise ValueError(f"noise must have shape {(n_noise, B, F_, S)}, got {tuple(noise.shape)}")
         cfg = gradient_scale > 0
-        gp, io = self.estimator.get_plan(B, S, 2 if cfg else 1, bool(speech_prompt), dev, ragged)
+        # One plan / hipGraph / workspace per BUCKET of lengths (Transformer.bucket_frames): the state, the noise and the
+        # condition are zero-padded to the bucket's frame count Sb and the true lengths go to the kernels through kv_len.
+        Sb = self.estimator.bucket_frames(S)
+        ragged = ragged or Sb != S
+        gp, io = self.estimator.get_plan(B, Sb, 2 if cfg else 1, bool(speech_prompt), dev, ragged)
         vl = (cond_lengths + 1).to(torch.int32)
         io["kv_len"].copy_(torch.cat([vl, vl]) if cfg else vl)
-        io["ids"].copy_(x)
-        io["cond"].copy_(cond)
+        if Sb != S:
+            io["ids"].zero_(); io["cond"].zero_()
+            noise = torch.nn.functional.pad(noise, (0, Sb - S))
+        io["ids"][:, :S].copy_(x)
+        io["cond"][:, :, :S].copy_(cond)
         condf = io["cond"]
         Z = noise[0].clone()
         v1 = torch.empty_like(Z)
         io["y"].copy_(Z)
+        S_true, S = S, Sb
         # time grid on the host in fp32, computed exactly as the reference does (voicebox.py:145,102,135)
         t_span = torch.linspace(0, 1, n + 1)
         t, dt = t_span[0], t_span[1] - t_span[0]
@@ -78,7 +86,7 @@ class CFM(BaseModule):
         for steps in range(1, n + 1):
             gp.run()
             if trace is not None:
-                trace.append(io["out"].clone())
+                trace.append(io["out"][:, :, :S_true].clone())
             t = t + dt
             c_eps, c_cond = float(1 - (1 - self.sigma_min) * t), float(t)
             last = steps == n
@@ -91,7 +99,7 @@ class CFM(BaseModule):
             if do_corr:
                 gp.run()
                 if trace is not None:
-                    trace.append(io["out"].clone())
+                    trace.append(io["out"][:, :, :S_true].clone())
                 eps = None
                 if speech_prompt:
                     eps, k = noise[k], k + 1
@@ -99,7 +107,7 @@ class CFM(BaseModule):
                                    z_commit=Z, t_next=float(t), **common)
             if not last:
                 dt = t_span[steps + 1] - t
-        return Z
+        return Z[:, :, :S_true].contiguous() if S_true != S else Z
 
 
 class Voicebox(CFM):

@@ -19,7 +19,13 @@ from torch.nn.utils import remove_weight_norm, weight_norm
 
 from ... import ops
 from ..._lib import ACT_TANH
+from ...graph import GraphedPlan
+from ...plancache import LRU, Arena, bucket
 from .env import AttrDict
+
+T_BUCKET = 64        # mel frames: lengths inside one bucket share ONE workspace (exact-length plans are re-parameterised on it)
+MAX_ARENAS = 3       # workspaces kept per model (~1.3 GB at 896 frames, f32); least recently used goes first
+MAX_PLANS = 4        # exact-length plans (+ hipGraphs) kept per workspace
 
 LRELU_SLOPE = 0.1
 
@@ -229,7 +235,7 @@ class BigVGAN(nn.Module):
             if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
                 m.weight_v.data.normal_(0.0, 0.01) if hasattr(m, "weight_v") else m.weight.data.normal_(0.0, 0.01)
         self._packed = None
-        self._plans = {}
+        self._plans = LRU(MAX_ARENAS)      # (frame bucket, device) -> (Arena, LRU of exact-length plans)
 
     # ------------------------------------------------------------------ reference API
     def remove_weight_norm(self):
@@ -245,7 +251,7 @@ class BigVGAN(nn.Module):
 
     def invalidate(self):
         """Drop packed weights / plans (call after changing parameters)."""
-        self._packed, self._plans = None, {}
+        self._packed, self._plans = None, LRU(MAX_ARENAS)
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -311,12 +317,13 @@ class BigVGAN(nn.Module):
         P["logscale"] = bool(h.snake_logscale)
         return P
 
-    def _build_plan(self, T, dev):
+    def _build_plan(self, T, dev, arena):
         h, P = self.h, self._packed
         plan = ops.Plan()
-        z32 = lambda *s: plan.hold(torch.zeros(*s, device=dev, dtype=torch.float32))
+        arena.begin()
+        z32 = lambda *s: arena.zeros(*s, dtype=torch.float32)
         f32 = self.compute_dtype == torch.float32
-        z16 = lambda *s: plan.hold(torch.zeros(*s, device=dev, dtype=self.compute_dtype))  # MFMA operand buffers
+        z16 = lambda *s: arena.zeros(*s, dtype=self.compute_dtype)  # MFMA operand buffers
         ok = lambda t: dict(out32=t) if f32 else dict(out16=t)  # route a kernel output to an operand buffer
         taps, taps_dn, ls = P["taps"], P["taps_dn"], P["logscale"]
         mels_pad = _pad32(h.num_mels)
@@ -391,15 +398,25 @@ class BigVGAN(nn.Module):
         if self._packed is None:
             self._packed = self._pack(dev)
         B, _, T = x.shape
-        key = (T, dev.index)
-        if key not in self._plans:
-            self._plans[key] = self._build_plan(T, dev)
-        plan, io = self._plans[key]
+        Tb = bucket(T, T_BUCKET)
+
+        def new_arena():
+            a = Arena(dev)
+            if Tb != T:
+                self._build_plan(Tb, dev, a)      # reserve the workspace at the bucket's capacity
+            return a, LRU(MAX_PLANS)
+        arena, plans = self._plans.get_or_build((Tb, dev.index), new_arena)
+
+        def new_plan():
+            plan, io = self._build_plan(T, dev, arena)
+            return GraphedPlan(plan), io
+        gp, io = plans.get_or_build(T, new_plan)
+        arena.take(gp)                            # another length ran on this workspace last -> back to all-zero
         outs = []
         for b in range(B):
             ops.cf_to_cl(x[b:b + 1].contiguous().float(), B=1, C=self.h.num_mels, T=T, Cpad=io["mel16"].shape[1],
                          scale=_scale, shift=_shift,
                          **(dict(out32=io["mel16"]) if self.compute_dtype == torch.float32 else dict(out16=io["mel16"])))
-            plan.run()
-            outs.append(io["out"].clone() if B > 1 else io["out"])
+            gp.run()
+            outs.append(io["out"].clone())        # a NEW tensor, as the reference returns (the plan's buffer is reused)
         return outs[0] if B == 1 else torch.cat(outs, 0)
