@@ -197,12 +197,23 @@ def test_prefix_kv_reuse(dev, tp_seg):
     import torch.distributed as dist
     from oracle import mistral_oracle as MO
     from usdm_amd.llm import USDMForCausalLM
-    kw = {}
+    kw, created = {}, False
     if tp_seg:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            created = True
         kw = dict(tp_segments=True, group=dist.group.WORLD)
+    try:
+        _prefix_kv_reuse_body(dev, kw)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def _prefix_kv_reuse_body(dev, kw):
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
     sd = MO.random_state_dict(SMALL, seed=21)
     a = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw)
     b = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256, **kw)

@@ -104,6 +104,8 @@ def sample(user_path, reference_path, model, unit_extractor, voicebox, vocoder, 
     agent_unit = torch.LongTensor(matches).to(device)
     reference_unit = None
     if reference_mel is not None:
+        if reference_path is None:
+            raise ValueError("reference_mel needs reference_path too (the prompt's unit ids are extracted from that audio)")
         ref_wav = load_audio_16k(reference_path)
         reference_unit = unit_extractor.predict(torch.as_tensor(ref_wav, dtype=torch.float32).to(device), 35 - 1)
         reference_path = None
@@ -113,12 +115,51 @@ def sample(user_path, reference_path, model, unit_extractor, voicebox, vocoder, 
     return audio
 
 
-if __name__ == "__main__":
+def load_models(model_cache_dir, dev=None, ctx_max=None):
+    """What the reference's __main__ does between argument parsing and sample() (src/inference.py:105-129), from LOCAL copies:
+    hub names resolve inside model_cache_dir (huggingface_hub cache layout or plain <name>/ directories, checkpoints.py)."""
+    import os
+    from .checkpoints import resolve_local
+    from .llm import USDMForCausalLM
+    from .unit_extractor import UnitExtractor
+    dev = torch.device(dev or device)
+    # Load voicebox, vocoder configuration and checkpoint
+    voicebox, vocoder = initialize_decoder(model_cache_dir, dev)
+    # Load unit extractor (speech tokenizer): the reference's own call, resolved inside the cache directory
+    os.environ.setdefault("USDM_MODEL_CACHE_DIR", model_cache_dir)
+    unit_extractor = UnitExtractor("xlsr2_1b_v2", "https://dl.fbaipublicfiles.com/seamlessM4T/models/unit_extraction/kmeans_10k.npy",
+                                   device=dev, cache_dir=model_cache_dir)
+    # Load USDM model and tokenizer
+    llm_dir = resolve_local(model_cache_dir, "naver-ai/USDM-DailyTalk", must_contain=("config.json",))
+    from transformers import AutoTokenizer
+    tokenizer = AutoTokenizer.from_pretrained(llm_dir, local_files_only=True)
+    want = ctx_max or min(int(getattr(tokenizer, "model_max_length", 4096) or 4096), 4096)
+    model = USDMForCausalLM.from_pretrained(llm_dir, device=dev, torch_dtype=torch.bfloat16, ctx_max=want).to(dev).eval()
+    return model, unit_extractor, voicebox, vocoder, tokenizer
+
+
+def main(argv=None):
+    global device
     parser = argparse.ArgumentParser()
-    parser.add_argument('--input_path', type=str, required=True, help="Path to the input file containing the speech data to process.")
-    parser.add_argument('--reference_path', type=str, default=None, help="Reference audio for speaker adaptation (needs the mel front end, SURVEY.md §8f).")
-    parser.add_argument('--model_cache_dir', type=str, required=True, help="Directory holding the local checkpoints.")
-    parser.add_argument('--output_path', type=str, required=True, help="Path to save the spoken response.")
-    args = parser.parse_args()
-    raise SystemExit("usdm_amd.inference: checkpoint loading from --model_cache_dir needs the converted local checkpoints "
-                     "(see INTEGRATION.md); call sample(...) with loaded model objects.")
+    parser.add_argument('--input_path', type=str, required=True,
+                        help="Path to the input file containing the speech data to process.")
+    parser.add_argument('--reference_path', type=str, default=None,
+                        help="Path to the reference audio file for speaker adaptation (optional). If not provided, the model will perform speaker unconditional generation.")
+    parser.add_argument('--model_cache_dir', type=str, required=True,
+                        help="Directory holding the model checkpoints (the reference's download cache, or local <name>/ directories).")
+    parser.add_argument('--output_path', type=str, required=True,
+                        help="Path to save the spoken response.")
+    args = parser.parse_args(argv)
+
+    device = torch.device("cuda")
+    model, unit_extractor, voicebox, vocoder, tokenizer = load_models(args.model_cache_dir, device)
+    try:
+        sample(args.input_path, args.reference_path, model, unit_extractor, voicebox, vocoder, tokenizer, args.output_path)
+    except Exception as e:       # the reference swallows sampling errors the same way (src/inference.py:131-134)
+        print(f"Error while sampling: {e}")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

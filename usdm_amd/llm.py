@@ -16,6 +16,7 @@ Host side: Python plans of C-ABI launches (libusdm_hip.so).
 Weights: HF state-dict key names (model.layers.N.self_attn.q_proj.weight, ...), bf16.
 """
 import math
+import os
 
 import torch
 
@@ -145,6 +146,39 @@ class USDMForCausalLM:
         m.W = m._shard(lambda n: sd[n])
         m._alloc()
         return m
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, device="cuda", cache_dir=None, torch_dtype=torch.bfloat16, **kw):
+        """Load an HF-format Mistral checkpoint directory (config.json + [sharded] safetensors or .bin), as the reference does
+        with AutoModelForCausalLM.from_pretrained('naver-ai/USDM-DailyTalk', cache_dir=..., torch_dtype=bf16)
+        (src/inference.py:116-123).  Hub names resolve inside cache_dir (no network).  Tensors stream from the memory-mapped
+        shards to the GPU one at a time; a tensor-parallel rank slices its shard on the way (tp_rank / tp_size in **kw)."""
+        from .checkpoints import TensorSource, read_mistral_config, resolve_local
+        if torch_dtype != torch.bfloat16:
+            raise NotImplementedError("the decode kernels stream bf16 weights (the reference loads torch_dtype=torch.bfloat16)")
+        path = pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            if cache_dir is None:
+                raise FileNotFoundError(f"{path}: not a directory, and no cache_dir to resolve the hub name in (no network)")
+            path = resolve_local(cache_dir, path, must_contain=("config.json",))
+        for drop in ("attn_implementation", "device_map", "low_cpu_mem_usage"):     # the reference's HF-only knobs
+            kw.pop(drop, None)
+        cfg = read_mistral_config(path)
+        m = cls(cfg, device, **kw)
+        src = TensorSource(path)
+        m.W = m._shard(src)
+        m._alloc()
+        m.name_or_path = path
+        return m
+
+    def to(self, device):
+        """The reference calls .to(device) on the loaded model (inference.py:123); weights already live on the GPU."""
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("USDMForCausalLM (usdm_amd) runs on the MI355X only; there is no CPU fallback")
+        return self
+
+    def eval(self):
+        return self
 
     @classmethod
     def random_init(cls, cfg, device, seed=0, **kw):

@@ -180,6 +180,8 @@ def self_test(comm, group, device, rounds=4, N=1024, K=512):
     import torch.distributed as dist
     from . import ops
     try:
+        if comm.n_sites < 2:
+            return "self-test needs at least two sites (rows + token pick)"
         rank, world = comm.rank, comm.world
         staged = dist.get_backend(group) == "gloo"
         g = torch.Generator().manual_seed(1000 + rank)
@@ -197,7 +199,7 @@ def self_test(comm, group, device, rounds=4, N=1024, K=512):
                 tot = part.clone(); dist.all_reduce(tot, group=group)
             want = (h0.float() + tot.to(torch.bfloat16).float()).to(torch.bfloat16)
             h = h0.clone()
-            ops.gemv(W, x, N=N, K=K, residual=h, y16=h, p2p=comm, p2p_site=it % comm.n_sites, p2p_mode=1)
+            ops.gemv(W, x, N=N, K=K, residual=h, y16=h, p2p=comm, p2p_site=it % (comm.n_sites - 1), p2p_mode=1)   # (the last site is the token pick's)
             torch.cuda.synchronize()
             err, _ = comm.status()
             if err:

@@ -37,23 +37,43 @@ def _frames(n, cfg):
 
 class UnitExtractor:
     def __init__(self, model_name_or_card, kmeans_uri, device=None, dtype=torch.float32, config=None,
-                 state_dict=None, centroids=None):
+                 state_dict=None, centroids=None, cache_dir=None):
         if dtype != torch.float32:
             raise NotImplementedError("the tokenizer path is fp32 (bit-exact ids are the contract); got %s" % dtype)
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("UnitExtractor (usdm_amd) runs on the MI355X only; there is no CPU fallback")
         self.cfg = dict(config or XLSR_1B)
+        # The reference passes a model CARD name and a URL (src/inference.py:111-113).  Offline they resolve to files of the same
+        # name inside cache_dir (or $USDM_MODEL_CACHE_DIR): <dir>/xlsr2_1b_v2[.pt|.safetensors|/] and <dir>/kmeans_10k.npy.
+        cache_dir = cache_dir or os.environ.get("USDM_MODEL_CACHE_DIR")
+        if cache_dir and state_dict is None and isinstance(model_name_or_card, str) and not os.path.exists(model_name_or_card):
+            for c in (model_name_or_card, model_name_or_card + ".pt", model_name_or_card + ".safetensors", model_name_or_card + ".bin"):
+                if os.path.exists(os.path.join(cache_dir, c)):
+                    model_name_or_card = os.path.join(cache_dir, c)
+                    break
+        if cache_dir and centroids is None and isinstance(kmeans_uri, str) and not os.path.exists(kmeans_uri):
+            c = os.path.join(cache_dir, os.path.basename(kmeans_uri))
+            if os.path.exists(c):
+                kmeans_uri = c
         if state_dict is None:
             if not (isinstance(model_name_or_card, str) and os.path.exists(model_name_or_card)):
                 raise FileNotFoundError(f"{model_name_or_card}: model cards / URLs cannot be fetched offline; pass a local "
-                                        "state-dict file (HF Wav2Vec2Model key names) or state_dict=")
-            state_dict = torch.load(model_name_or_card, map_location="cpu")
+                                        "checkpoint (file or directory; HF Wav2Vec2Model or fairseq2 key names) or state_dict=")
+            from .checkpoints import TensorSource, convert_w2v_keys
+            state_dict = convert_w2v_keys(TensorSource(model_name_or_card).state_dict())
+            cj = os.path.join(model_name_or_card, "config.json") if os.path.isdir(model_name_or_card) else None
+            if config is None and cj and os.path.exists(cj):     # an HF Wav2Vec2 directory carries its own sizes
+                import json
+                with open(cj) as f:
+                    hc = json.load(f)
+                self.cfg.update({k: (tuple(hc[k]) if isinstance(hc[k], list) else hc[k]) for k in XLSR_1B if k in hc})
         if centroids is None:
             if not (isinstance(kmeans_uri, str) and os.path.exists(kmeans_uri)):
                 raise FileNotFoundError(f"{kmeans_uri}: URLs cannot be fetched offline; pass a local .npy or centroids=")
             centroids = torch.from_numpy(np.load(kmeans_uri))
-        self._pack(state_dict, centroids)
+        from .checkpoints import convert_w2v_keys
+        self._pack(convert_w2v_keys(state_dict), centroids)
         self._plans = LRU(MAX_ARENAS)     # (sample bucket, layer) -> (Arena, LRU of exact-length plans)
         self.last_io = None
         self.last_margin = None

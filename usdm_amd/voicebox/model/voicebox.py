@@ -130,6 +130,9 @@ class Voicebox(CFM):
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, cache_dir=None, **kw):
         d = pretrained_model_name_or_path
+        if not os.path.isdir(d) and cache_dir is not None:      # the reference's call: hub name + cache_dir (model_util.py:59-62)
+            from ...checkpoints import resolve_local
+            d = resolve_local(cache_dir, d, ("config.json",))
         if not os.path.isdir(d):
             raise FileNotFoundError(f"{d}: only local directories can be loaded (no network); expected config.json + weights")
         with open(os.path.join(d, "config.json")) as f:

@@ -58,8 +58,11 @@ def process_unit(unit, hps, device):
 
 
 def initialize_decoder(model_cache_dir, device):
-    voicebox = Voicebox.from_pretrained(os.path.join(model_cache_dir, "xlsr-token-Voicebox")).to(device).eval()
-    vocoder = BigVGAN.from_pretrained(os.path.join(model_cache_dir, "bigvgan_22khz_80band")).to(device).eval()
+    """model_util.py:57-69: both models .eval(), the vocoder's weight norm removed.  The hub names resolve inside
+    model_cache_dir (huggingface_hub cache layout or <dir>/<name>/; usdm_amd/checkpoints.py)."""
+    from ...checkpoints import resolve_local
+    voicebox = Voicebox.from_pretrained(resolve_local(model_cache_dir, "naver-ai/xlsr-token-Voicebox", ("config.json",))).to(device).eval()
+    vocoder = BigVGAN.from_pretrained(resolve_local(model_cache_dir, "nvidia/bigvgan_22khz_80band", ("config.json",))).to(device).eval()
     vocoder.remove_weight_norm()
     return voicebox, vocoder
 

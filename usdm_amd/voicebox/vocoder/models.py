@@ -268,6 +268,9 @@ class BigVGAN(nn.Module):
         """Local-directory loading of `config.json` + `bigvgan_generator.pt['generator']`
         (reference: models.py:234-313; hub download is not available offline)."""
         d = pretrained_model_name_or_path
+        if not os.path.isdir(d) and cache_dir is not None:      # the reference's call: hub name + cache_dir (model_util.py:64-67)
+            from ...checkpoints import resolve_local
+            d = resolve_local(cache_dir, d, ("config.json",))
         if not os.path.isdir(d):
             raise FileNotFoundError(f"{d}: only local directories can be loaded (no network); expected config.json + bigvgan_generator.pt")
         h = load_hparams_from_json(os.path.join(d, "config.json"))
