@@ -235,6 +235,11 @@ typedef struct usdm_gemv_args {
    * bf16(sum)): the all-reduce, the residual add and the bf16 rounding of HF's residual stream in one epilogue, no
    * collective launch.  p2p_mode 2 (split): write only; usdm_allreduce_p2p_reduce finishes.  Needs residual and y16. */
   const struct usdm_p2p_dev* p2p; int32_t p2p_site, p2p_mode;
+  /* o_proj of the decode step: x is not read from memory but MERGED here, in the x-staging prologue, from the context-split
+   * partials usdm_attn_decode left (defer_merge): x[h*128+d] = bf16( sum_s po[h][s][d]*w_s / sum_s pl[h][s]*w_s ),
+   * w_s = exp(pm[h][s] - max_s pm[h][s]).  Replaces the separate combine launch (the prologue runs while this launch's first
+   * weight loads are in flight).  K = heads*128; mrg_ns splits per head. */
+  const float* mrg_pm; const float* mrg_pl; const float* mrg_po; int32_t mrg_ns;
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
@@ -325,6 +330,8 @@ typedef struct usdm_attn_decode_args {
    * b*cache_bs, writes out + b*out_bs (element strides); scratch is [batch][Hq][NS]...; counters [batch][Hkv]. NS > 1. */
   int32_t batch; int64_t qkv_bs, out_bs, cache_bs;
   const int32_t* skip;  /* optional (single-sequence form): *skip != 0 -> return immediately */
+  int32_t defer_merge;  /* NS > 1, no counters: leave the partials (pm, pl, po) for the consumer (usdm_gemv mrg_*): no combine
+                           launch, `out` is not written */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

@@ -104,6 +104,20 @@ def test_attn_decode(dev, ctx):
     assert (out1.cpu().double() - ref).abs().max() <= 2e-2 * ref.abs().max()
     # the new K/V row was appended
     assert torch.equal(kcd[:, pos].cpu(), kr) and torch.equal(vcd[:, pos].cpu(), v)
+    # partials left for the consumer (defer_merge) and merged inside a GEMV's x-staging prologue (the o_proj of the decode
+    # step): with W = identity the GEMV returns exactly the merged, bf16-rounded attention output
+    for ns in (8, 3):
+        pm2, pl2, po2 = torch.zeros(Hq * ns, device=dev), torch.zeros(Hq * ns, device=dev), torch.zeros(Hq * ns * d, device=dev)
+        ops.attn_decode(qkv.to(dev), torch.tensor([pos], dtype=torch.int32, device=dev), cos.to(dev), sin.to(dev), kc.to(dev), vc.to(dev),
+                        pm2, pl2, po2, None, Hq=Hq, Hkv=Hkv, ctx_max=ctx_max, NS=ns, scale=d ** -0.5, defer_merge=True)
+        eye = torch.eye(Hq * d, dtype=bf, device=dev)
+        y = torch.zeros(Hq * d, dtype=bf, device=dev)
+        ops.gemv(eye, y, N=Hq * d, K=Hq * d, y16=y.clone(), merge=(pm2, pl2, po2, ns))        # x pointer is ignored in merge mode
+        y2 = torch.zeros(Hq * d, dtype=bf, device=dev)
+        ops.gemv(eye, y, N=Hq * d, K=Hq * d, y16=y2, merge=(pm2, pl2, po2, ns))
+        assert (y2.cpu().double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+        if ns == NS:   # same partials as the combine kernel saw: equal up to the last bf16 bit (different summation order)
+            assert (y2.float() - out.float()).abs().max() <= 2 ** -7 * out.float().abs().max()
 
 
 def _compare_generate(dev, cfg, seed, L0, new, bad, eos=None):

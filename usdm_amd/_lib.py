@@ -110,6 +110,7 @@ class GemvArgs(C.Structure):
         ("ban", C.c_void_p), ("part_val", C.c_void_p), ("part_idx", C.c_void_p), ("idx_offset", C.c_int32),
         ("x_delta", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p),
         ("p2p", C.c_void_p), ("p2p_site", C.c_int32), ("p2p_mode", C.c_int32),
+        ("mrg_pm", C.c_void_p), ("mrg_pl", C.c_void_p), ("mrg_po", C.c_void_p), ("mrg_ns", C.c_int32),
     ]
 
 
@@ -160,6 +161,7 @@ class AttnDecodeArgs(C.Structure):
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
         ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
         ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64), ("skip", C.c_void_p),
+        ("defer_merge", C.c_int32),
     ]
 
 

@@ -117,6 +117,39 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   // 8 consecutive elements of the input vector; with x_delta the pending residual add of the tensor-parallel path is applied
   // on the fly (HF rounding: bf16(h + bf16(delta))) and workgroup 0 publishes the updated residual stream
   auto ldx = [&](int i, bool publish) -> u32x4 {
+    if (a.mrg_po) {
+      // o_proj of the decode step: merge the context-split attention partials of head i / 128 here (see usdm_gemv_args.mrg_*).
+      // All partial loads of a chunk of 8 splits are requested before the first is used.
+      const int hq = i >> 7, d = i & 127, NS = a.mrg_ns;
+      const float* pm = a.mrg_pm + hq * NS;
+      const float* pl = a.mrg_pl + hq * NS;
+      const float* po = a.mrg_po + (int64_t)hq * NS * 128 + d;
+      float m = -1e30f;
+      for (int s = 0; s < NS; ++s) m = fmaxf(m, pm[s]);
+      float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < NS; s0 += 8) {
+        float4 p0[8], p1[8];
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = min(s0 + u, NS - 1);
+          p0[u] = *(const float4*)(po + (int64_t)s * 128);
+          p1[u] = *(const float4*)(po + (int64_t)s * 128 + 4);
+          w[u] = (s0 + u < NS) ? __expf(pm[s] - m) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          l = fmaf((s0 + u < NS) ? pl[min(s0 + u, NS - 1)] : 0.f, w[u], l);
+          o[0] = fmaf(p0[u].x, w[u], o[0]); o[1] = fmaf(p0[u].y, w[u], o[1]); o[2] = fmaf(p0[u].z, w[u], o[2]); o[3] = fmaf(p0[u].w, w[u], o[3]);
+          o[4] = fmaf(p1[u].x, w[u], o[4]); o[5] = fmaf(p1[u].y, w[u], o[5]); o[6] = fmaf(p1[u].z, w[u], o[6]); o[7] = fmaf(p1[u].w, w[u], o[7]);
+        }
+      }
+      const float inv = 1.0f / l;
+      u32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = pack_bf2(o[2 * e] * inv, o[2 * e + 1] * inv);
+      return r;
+    }
     u32x4 v = *(const u32x4*)(xg + i);
     if (a.x_delta) {
       const float4 d0 = *(const float4*)(a.x_delta + i), d1 = *(const float4*)(a.x_delta + i + 4);
@@ -408,7 +441,7 @@ __global__ void rope_cache_kernel(const usdm_rope_args a) {
 // Decode attention, split over the context: grid (Hkv, NS).  Each block ropes the new q (G heads of
 // its kv head) and the new k itself, so no block depends on another block's cache write.
 // ---------------------------------------------------------------------------------------------
-constexpr int DA_KMAX = 256;  // max keys per split
+constexpr int DA_KMAX = 512;  // max keys per split
 template <int G>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode_args a) {
   __shared__ float qs[G][128];
@@ -822,7 +855,7 @@ __global__ void residual_add_kernel(bf16_t* h, const float* delta, int n) {
 }  // namespace
 
 extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
-  USDM_CHECK_ARG(pa && pa->W && pa->x, "usdm_gemv: null args");
+  USDM_CHECK_ARG(pa && pa->W && (pa->x || pa->mrg_po), "usdm_gemv: null args");
   const usdm_gemv_args& a = *pa;
   USDM_CHECK_ARG(a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "usdm_gemv: bad N/K/ldw");
   USDM_CHECK_ARG(a.K <= 16384, "usdm_gemv: K too large for the LDS-resident input vector");
@@ -832,6 +865,8 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(!a.part_val || (a.part_idx && !glu), "usdm_gemv: part_idx missing / lm_head mode is not GLU");
   USDM_CHECK_ARG(!a.norm_w || a.K % 8 == 0, "usdm_gemv: K");
   USDM_CHECK_ARG(!a.x_out || (a.x_delta && a.x_out != a.x), "usdm_gemv: x_out needs x_delta and must not alias x");
+  USDM_CHECK_ARG(!a.mrg_po || (a.mrg_pm && a.mrg_pl && a.mrg_ns >= 1 && a.mrg_ns <= 64 && a.K % 128 == 0 && !a.norm_w && !a.x_delta),
+                 "usdm_gemv: merged-attention input needs pm/pl/po, 1 <= splits <= 64, K a multiple of 128, no norm / x_delta");
   USDM_CHECK_ARG(a.p2p_mode >= 0 && a.p2p_mode <= 2, "usdm_gemv: p2p_mode");
   USDM_CHECK_ARG(!a.p2p_mode || (a.p2p && a.p2p_site >= 0 && a.act == USDM_ACT_NONE && !a.part_val && a.residual && a.y16),
                  "usdm_gemv: the fused all-reduce needs a plain row-parallel projection with residual + y16");
@@ -919,7 +954,8 @@ extern "C" int usdm_rope_cache(const usdm_rope_args* pa, usdm_stream_t stream) {
 }
 
 extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t stream) {
-  USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && pa->out, "usdm_attn_decode: null args");
+  USDM_CHECK_ARG(pa && pa->qkv && pa->pos && pa->kcache && pa->vcache && (pa->out || pa->defer_merge), "usdm_attn_decode: null args");
+  USDM_CHECK_ARG(!pa->defer_merge || (pa->NS > 1 && !pa->counters && pa->batch <= 1), "usdm_attn_decode: defer_merge needs NS > 1, no counters, one sequence");
   USDM_CHECK_ARG(pa->NS == 1 || (pa->pm && pa->pl && pa->po), "usdm_attn_decode: partial buffers missing");
   const usdm_attn_decode_args& a = *pa;
   USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0 && a.NS <= 64, "usdm_attn_decode: heads / NS (<= 64)");
@@ -953,7 +989,7 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);
   else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
   USDM_LAUNCH_CHECK();
-  if (!a.counters) {
+  if (!a.counters && !a.defer_merge) {
     hipLaunchKernelGGL(attn_combine_kernel, dim3(a.Hq, nbatch), dim3(128), 0, st, a.pm, a.pl, a.po, a.NS, (bf16_t*)a.out, a.out_bs, a.skip);
     USDM_LAUNCH_CHECK();
   }

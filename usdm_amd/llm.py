@@ -117,10 +117,14 @@ class USDMForCausalLM:
             raise NotImplementedError(f"ctx_max {self.ctx_max} exceeds the sliding window ({c.get('sliding_window', 4096)}): "
                                       "sliding-window attention is not implemented")
         import os
-        # decode attention: 1 = one 16-wave workgroup per kv head (no partials / combine launch); >1 = context split
-        self.NS = int(os.environ.get("USDM_DECODE_SPLITS", "32")) if decode_splits is None else decode_splits
-        if self.NS == 1 and self.ctx_max > 4096:
-            self.NS = 16
+        # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
+        # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
+        # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
+        self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "1") == "1"
+        dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
+        self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
+        if self.NS == 1:
+            self.merge_in_oproj = False          # one workgroup per kv head: nothing to merge
         self.W = None
         # bounded caches (plancache.LRU): prefill plans are keyed by exact prompt length (a plan is argument structs + ~60 KB of
         # workspace per token; no hipGraph), decode plans / graphs by {greedy, sampling} only
@@ -399,8 +403,10 @@ class USDMForCausalLM:
         pm, pl, po = Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS, dt=torch.float32), Z(Hq * self.NS * d, dt=torch.float32)
         skp, mode = self.st_done, (1 if self.p2p_fused else 2)
 
-        def row_parallel(plan, W, x, K, site):
-            ops.gemv(W, x, N=H, K=K, residual=h, y16=h, skip=skp, p2p=self.p2p, p2p_site=site, p2p_mode=mode, plan=plan)
+        mrg = (pm, pl, po, self.NS) if self.merge_in_oproj else None
+
+        def row_parallel(plan, W, x, K, site, merge=None):
+            ops.gemv(W, x, N=H, K=K, residual=h, y16=h, skip=skp, p2p=self.p2p, p2p_site=site, p2p_mode=mode, merge=merge, plan=plan)
             segs.append(plan)
             plan = ops.Plan()
             if mode == 2:
@@ -411,8 +417,8 @@ class USDMForCausalLM:
             w = self.W["layers"][l]
             ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, plan=plan)
-            plan = row_parallel(plan, w["o"], ao, Hq * d, 2 * l)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, defer_merge=mrg is not None, plan=plan)
+            plan = row_parallel(plan, w["o"], ao, Hq * d, 2 * l, merge=mrg)
             ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, skip=skp, plan=plan)
             plan = row_parallel(plan, w["down"], act, I, 2 * l + 1)
         self._lm_head_and_pick(plan, h, True, segs, None, skip=skp)
@@ -457,12 +463,13 @@ class USDMForCausalLM:
                 h, pend = flip(h), None
             else:
                 ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
+            mrg = (pm, pl, po, self.NS) if (self.merge_in_oproj and cnt is None) else None
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, defer_merge=mrg is not None, plan=plan)
             if tp == 1:
-                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, plan=plan)
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, merge=mrg, plan=plan)
             else:
-                ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, skip=skp, plan=plan)
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, skip=skp, merge=mrg, plan=plan)
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
                 plan = ops.Plan()
                 if fuse_res:

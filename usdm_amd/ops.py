@@ -209,7 +209,7 @@ def process_unit(units, rep, hop):
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
          ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, p2p=None, p2p_site=0,
-         p2p_mode=0, plan=None):
+         p2p_mode=0, merge=None, plan=None):
     """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h).  p2p: a usdm_amd.p2p.P2PComm (fused all-reduce)."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out, skip)
     if x_out is not None and x_out.data_ptr() == x.data_ptr():
@@ -221,6 +221,10 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
     a.x_delta, a.x_out, a.skip = _ptr(x_delta), _ptr(x_out), _ptr(skip)
+    if merge is not None:       # (pm, pl, po, NS): x is merged from the decode-attention partials in the prologue
+        pm, pl, po, ns = merge
+        _need_cuda(pm, pl, po)
+        a.mrg_pm, a.mrg_pl, a.mrg_po, a.mrg_ns = _ptr(pm), _ptr(pl), _ptr(po), ns
     if p2p is not None and p2p_mode:
         p2p.check_site(p2p_site, N)
         a.p2p, a.p2p_site, a.p2p_mode = p2p.dev_ptr, p2p_site, p2p_mode
@@ -310,13 +314,14 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
 
 
 def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,
-                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, plan=None):
+                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, defer_merge=False, plan=None):
     _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
     a.cos, a.sin, a.kcache, a.vcache = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache)
     a.pm, a.pl, a.po, a.out, a.counters = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out), _ptr(counters)
     a.batch, a.qkv_bs, a.out_bs, a.cache_bs, a.skip = batch, qkv_bs, out_bs, cache_bs, _ptr(skip)
+    a.defer_merge = int(defer_merge)
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
