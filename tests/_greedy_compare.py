@@ -39,3 +39,21 @@ def compare_greedy(model, dev, ids, ref, ref_logits, new, max_restarts=8, **gen_
         assert len(div) <= max_restarts, f"too many near-tie divergences: {div}"
         done = j + 1
     return div, new
+
+
+def check_against_oracle(out, ref, ref_logits, L0):
+    """One already-generated id list vs the oracle's: equal, or first difference at an oracle near-tie with the HIP pick inside
+    the tie band (no continuation past it).  Returns the index of the first difference among the generated tokens, or None."""
+    assert out[:L0] == ref[:L0]
+    n = min(len(out), len(ref))
+    first = next((i for i in range(L0, n) if out[i] != ref[i]), None)
+    if first is None:
+        assert len(out) == len(ref), (len(out), len(ref))
+        return None
+    lg = ref_logits[first - L0]
+    top = lg.max().item()
+    tol = NEAR_TIE_REL * abs(top) + NEAR_TIE_ABS
+    top2 = torch.topk(lg, 2).values
+    assert (top2[0] - top2[1]).item() <= tol, f"generated token {first - L0}: differs from the oracle away from a near-tie (gap {(top2[0] - top2[1]).item()})"
+    assert top - lg[out[first]].item() <= tol, f"generated token {first - L0}: HIP pick outside the oracle's near-tie band"
+    return first - L0

@@ -60,3 +60,28 @@ def test_generate_batch_equals_generate(dev):
     for s, b in zip(singles, batch):
         assert torch.equal(s, b), (s.shape, b.shape)
     assert singles[1].shape[1] <= 17 + 10
+
+
+def test_generate_batch_vs_oracle(dev):
+    """Batched decode against the CPU ORACLE (not against the single-sequence HIP path): every sequence of a 5-prompt batch
+    (groups of 4 + 1, ragged lengths, ban mask, an EOS that stops one sequence early) equals oracle greedy generation of that
+    prompt, up to oracle near-ties."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    cfg = dict(vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=32768)
+    sd = MO.random_state_dict(cfg, seed=17)
+    m = USDMForCausalLM.from_state_dict(sd, cfg, dev, ctx_max=256)
+    gen = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(0, 1000, (L,), generator=gen) for L in (40, 17, 65, 33, 50)]
+    bad = [[i] for i in range(0, 300)]
+    probe = MO.greedy_generate(sd, cfg, prompts[1], 30, bad_words_ids=bad)
+    eos = probe[17 + 9]                                        # prompt 1 stops at its 10th generated token (or earlier)
+    refs = [MO.greedy_generate(sd, cfg, p, 30, bad_words_ids=bad, eos_token_id=eos, return_logits=True) for p in prompts]
+    batch = m.generate_batch([p[None].to(dev) for p in prompts], max_new_tokens=30, bad_words_ids=bad, eos_token_id=eos)
+    firsts = []
+    for p, (ref, ref_logits), out in zip(prompts, refs, batch):
+        firsts.append(check_against_oracle(out[0].tolist(), ref, ref_logits, p.numel()))
+    print("batched decode vs oracle: first differences (None = identical):", firsts)
+    assert len(refs[1][0]) <= 17 + 10

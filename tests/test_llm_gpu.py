@@ -276,3 +276,27 @@ def test_device_side_eos(dev):
     # min_new_tokens defers the stop
     c = m.generate(input_ids=ids, max_new_tokens=40, eos_token_id=eos, min_new_tokens=first + 2)
     assert c.shape[1] > a.shape[1] and torch.equal(c[0, :a.shape[1]], free[0, :a.shape[1]])
+
+
+def test_prefix_kv_reuse_vs_oracle(dev):
+    """Prefix-KV reuse across the three chained rounds of src/inference.py:61-83 against the CPU ORACLE: each round's prompt is the
+    previous round's output plus a few tokens; with reuse on, only the new tokens are prefilled, and the generated ids must equal
+    oracle greedy generation of the FULL prompt (recomputed from scratch, as the reference does), up to oracle near-ties."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    sd = MO.random_state_dict(SMALL, seed=23)
+    m = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256)
+    m.reuse_prefix = True
+    g = torch.Generator().manual_seed(6)
+    p = torch.randint(0, 1000, (60,), generator=g)
+    bad = [[i] for i in range(500, 700)]
+    firsts = []
+    for rnd, (new, extra) in enumerate([(12, 4), (10, 2), (18, 0)]):
+        ref, ref_logits = MO.greedy_generate(sd, SMALL, p, new, bad_words_ids=bad, return_logits=True)
+        out = m.generate(input_ids=p[None].to(dev), max_new_tokens=new, bad_words_ids=bad)[0].cpu()
+        firsts.append(check_against_oracle(out.tolist(), ref, ref_logits, p.numel()))
+        if rnd:
+            assert any(k[1] > 0 for k in m._prefill_plans), "the round did not reuse the cached prefix"
+        p = torch.cat([out, torch.randint(0, 1000, (extra,), generator=g)])      # next prompt extends what the cache holds
+    print("prefix reuse vs oracle: first differences per round (None = identical):", firsts)

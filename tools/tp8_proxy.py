@@ -11,7 +11,12 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 tp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-llm = synth.make_llm(dev, ctx_max=2048, tp_rank=0, tp_size=tp, group=dist.group.WORLD, tp_segments=True)
+comm = None
+if os.environ.get("USDM_TP_COMM", "rccl") == "p2p":     # the peer-to-peer decode path: rank 0 exchanges with itself only (world 1)
+    os.environ["USDM_P2P_PROXY"] = "1"
+    from usdm_amd.p2p import P2PComm
+    comm = P2PComm.in_process(1, 65, 4096)[0]
+llm = synth.make_llm(dev, ctx_max=2048, tp_rank=0, tp_size=tp, group=dist.group.WORLD, tp_segments=True, p2p=comm)
 
 def gather():   # 1-rank stand-in for the all_gather of the vocab-parallel partial arg-max
     n = llm.nparts

@@ -42,7 +42,10 @@ __device__ unsigned long long g_gemv_trace[8192 * 8];
 #define GTR(i) do { } while (0)
 #endif
 
-template <int RW, bool GLU, int NWV>
+// MRG: the merged-attention input form (usdm_gemv_args.mrg_*) is a separate instantiation: its 16 partial loads per thread cost
+// ~64 VGPRs, which lowered the occupancy of EVERY shape when the branch lived in the common kernel (measured: all GEMVs 20-30 %
+// slower, profiles/r02_decode_ablation.txt).
+template <int RW, bool GLU, int NWV, bool MRG = false>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
   constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
@@ -117,39 +120,6 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   // 8 consecutive elements of the input vector; with x_delta the pending residual add of the tensor-parallel path is applied
   // on the fly (HF rounding: bf16(h + bf16(delta))) and workgroup 0 publishes the updated residual stream
   auto ldx = [&](int i, bool publish) -> u32x4 {
-    if (a.mrg_po) {
-      // o_proj of the decode step: merge the context-split attention partials of head i / 128 here (see usdm_gemv_args.mrg_*).
-      // All partial loads of a chunk of 8 splits are requested before the first is used.
-      const int hq = i >> 7, d = i & 127, NS = a.mrg_ns;
-      const float* pm = a.mrg_pm + hq * NS;
-      const float* pl = a.mrg_pl + hq * NS;
-      const float* po = a.mrg_po + (int64_t)hq * NS * 128 + d;
-      float m = -1e30f;
-      for (int s = 0; s < NS; ++s) m = fmaxf(m, pm[s]);
-      float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int s0 = 0; s0 < NS; s0 += 8) {
-        float4 p0[8], p1[8];
-        float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int s = min(s0 + u, NS - 1);
-          p0[u] = *(const float4*)(po + (int64_t)s * 128);
-          p1[u] = *(const float4*)(po + (int64_t)s * 128 + 4);
-          w[u] = (s0 + u < NS) ? __expf(pm[s] - m) : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          l = fmaf((s0 + u < NS) ? pl[min(s0 + u, NS - 1)] : 0.f, w[u], l);
-          o[0] = fmaf(p0[u].x, w[u], o[0]); o[1] = fmaf(p0[u].y, w[u], o[1]); o[2] = fmaf(p0[u].z, w[u], o[2]); o[3] = fmaf(p0[u].w, w[u], o[3]);
-          o[4] = fmaf(p1[u].x, w[u], o[4]); o[5] = fmaf(p1[u].y, w[u], o[5]); o[6] = fmaf(p1[u].z, w[u], o[6]); o[7] = fmaf(p1[u].w, w[u], o[7]);
-        }
-      }
-      const float inv = 1.0f / l;
-      u32x4 r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = pack_bf2(o[2 * e] * inv, o[2 * e + 1] * inv);
-      return r;
-    }
     u32x4 v = *(const u32x4*)(xg + i);
     if (a.x_delta) {
       const float4 d0 = *(const float4*)(a.x_delta + i), d1 = *(const float4*)(a.x_delta + i + 4);
@@ -191,6 +161,41 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
         }
       }
       *(u32x4*)(xs + i) = o;
+    }
+  } else if constexpr (MRG) {
+    // o_proj of the decode step: x is MERGED here from the context-split attention partials (usdm_gemv_args.mrg_*), four
+    // elements of one head per thread; the partial loads of a chunk of 8 splits are requested before the first is used.
+    const int NS = a.mrg_ns;
+    for (int i = tid * 4; i < Kpad; i += NTH * 4) {
+      u32x2 r = {0u, 0u};
+      if (i < K) {
+        const int hq = i >> 7, d = i & 127;
+        const float* pm = a.mrg_pm + hq * NS;
+        const float* pl = a.mrg_pl + hq * NS;
+        const float* po = a.mrg_po + (int64_t)hq * NS * 128 + d;
+        float m = -1e30f;
+        for (int s = 0; s < NS; ++s) m = fmaxf(m, pm[s]);
+        float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        for (int s0 = 0; s0 < NS; s0 += 8) {
+          float4 p[8];
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int s = min(s0 + u, NS - 1);
+            p[u] = *(const float4*)(po + (int64_t)s * 128);
+            w[u] = (s0 + u < NS) ? __expf(pm[s] - m) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            l = fmaf((s0 + u < NS) ? pl[min(s0 + u, NS - 1)] : 0.f, w[u], l);
+            o0 = fmaf(p[u].x, w[u], o0); o1 = fmaf(p[u].y, w[u], o1); o2 = fmaf(p[u].z, w[u], o2); o3 = fmaf(p[u].w, w[u], o3);
+          }
+        }
+        const float inv = 1.0f / l;
+        r[0] = pack_bf2(o0 * inv, o1 * inv);
+        r[1] = pack_bf2(o2 * inv, o3 * inv);
+      }
+      *(u32x2*)(xs + i) = r;
     }
   } else {
     for (int i = tid * 8; i < Kpad; i += NTH * 8) {
@@ -877,6 +882,13 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   const size_t lds = (size_t)Kpad * 2;
   // Wide workgroups for the mid-size projections: one workgroup per CU with 12-16 waves stages x (and the fused
   // RMSNorm) once per 16-24 rows instead of once per 4, at the same number of loads in flight.
+  if (a.mrg_po) {   // o_proj with the attention merge in its prologue: the 7B shape (4096 outputs) or the general form
+    USDM_CHECK_ARG(!glu && !a.part_val, "usdm_gemv: merged-attention input is for plain projections");
+    if (nout % 256 == 0 && nout / 256 == 16) hipLaunchKernelGGL((gemv_kernel<1, false, 16, true>), dim3(256), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, false, 4, true>), dim3(cdiv(nout, 4)), dim3(256), lds, st, a);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
   if (!glu && !a.part_val && nout % 256 == 0) {
     const int rows_per_cu = nout / 256;
     if (rows_per_cu == 16) {

@@ -98,7 +98,7 @@ class USDMForCausalLM:
         if p2p is not None:
             if not self.tp_path:
                 raise ValueError("p2p needs the tensor-parallel path (tp_size > 1 or tp_segments=True)")
-            if (p2p.rank, p2p.world) != (tp_rank, tp_size):
+            if (p2p.rank, p2p.world) != (tp_rank, tp_size) and os.environ.get("USDM_P2P_PROXY") != "1":   # (tools/tp8_proxy.py)
                 raise ValueError(f"P2PComm is rank {p2p.rank}/{p2p.world}, the model shard is rank {tp_rank}/{tp_size}")
             if p2p.n_sites < 2 * c["num_hidden_layers"] + 1 or p2p.max_elems < c["hidden_size"]:
                 raise ValueError("P2PComm too small: needs 2*layers+1 sites of hidden_size elements")
@@ -120,7 +120,12 @@ class USDMForCausalLM:
         # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
         # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
         # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
-        self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "1") == "1"
+        # Measured (profiles/r02_decode_ablation.txt) and OFF by default: on the single-GPU 7B shapes the merge costs the o_proj
+        # launch more than the combine launch it removes (2.97 -> 3.10 ms/token at NS = 8: 128 KB of partials per workgroup and
+        # two dependent L2 round trips no longer hide under the weight ring; NS = 32: 3.28), and the fewer, fatter splits it
+        # wants make the latency-bound split kernel slower (rank-0-of-8 proxy: 1.10 -> 1.23 ms/token).  USDM_ATTN_MERGE_IN_OPROJ=1
+        # enables it.
+        self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
         dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
         if self.NS == 1:
@@ -134,6 +139,7 @@ class USDMForCausalLM:
         self._batches = {}
         self._ban_cache = LRU(8)
         self.stats = {}
+        self.logits_hook = None   # generate(_logits_hook=f): f() runs between the lm_head launch and the sampling pick of every step
         self.keep_logits = False  # debug/tests: keep the fp32 (bf16-valued) logits of the last step
         self.last_logits = None
 
@@ -305,6 +311,10 @@ class USDMForCausalLM:
         if sampling:
             if self.tp_path:
                 raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
+            if sampling == "hook":      # Python logits processors (usdm_amd.serving): a host call between the two kernels
+                segs.append(plan)
+                segs.append(lambda: self.logits_hook())
+                plan = ops.Plan()
             ops.sample_final(self.last_logits, st, dev_params=self.sample_params,
                              embed=self.W["embed"], h_out=self.h_dec, Hd=c["hidden_size"], plan=plan)
             plan.hold(st)
@@ -634,7 +644,7 @@ class USDMForCausalLM:
         self._ban_cache.put(key, (bad_words_ids, t))
         return t
 
-    def _setup_call(self, input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens):
+    def _setup_call(self, input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens, ban_mask=None):
         """Per-call device state of generate(): prompt ids into the (cached) prefill plan, ban mask, position / step counters,
         device-side EOS list.  Returns (prefill segments, the EOS ids the device checks)."""
         L0 = input_ids.shape[1]
@@ -642,7 +652,10 @@ class USDMForCausalLM:
         segs, io = self._prefill_plans.get_or_build(key, lambda: self._build_prefill(L0 - past, sampling, past=past))
         io["ids"].copy_(input_ids[0, past:])
         self._kv_ids, self._vt_upto = None, L0      # (set again once this call's decode steps are known)
-        self.ban.copy_(self._ban_mask(bad_words_ids))
+        if ban_mask is not None:      # a ready-made [vocab] 0/1 mask (usdm_amd.serving: static logits processors)
+            self.ban.copy_(ban_mask.to(torch.uint8)[self.v0:self.v1])
+        else:
+            self.ban.copy_(self._ban_mask(bad_words_ids))
         self.st_pos.fill_(L0)
         self.st_step.zero_()
         eos_list = sorted(set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])) if eos_token_id is not None else []
@@ -653,7 +666,8 @@ class USDMForCausalLM:
 
     @torch.no_grad()
     def generate(self, input_ids=None, max_length=None, do_sample=False, bad_words_ids=None, top_p=1.0, top_k=None,
-                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, seed=None, **unused):
+                 temperature=1.0, eos_token_id=None, max_new_tokens=None, min_new_tokens=0, seed=None, ban_mask=None,
+                 _logits_hook=None, **unused):
         """Generation with the call shape of src/inference.py:63-83.  Greedy when do_sample is False or top_k == 1 (what the
         reference passes: arg-max of the ban-masked logits).  Otherwise temperature / top-k / top-p sampling on the device
         (usdm_sample_final).  `seed` keys its Philox stream; seed=None draws a fresh one from torch's global CPU generator,
@@ -661,7 +675,13 @@ class USDMForCausalLM:
         if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
             raise ValueError("input_ids must be a LongTensor of shape [1, L] (batch 1, as the reference calls it)")
         sampling = False
-        if do_sample and top_k != 1:
+        if _logits_hook is not None:      # arbitrary Python logits processors: eager steps, knobs still on the device
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            sampling, self.logits_hook = "hook", _logits_hook
+            ops.set_sample_params(self.sample_params, temperature if do_sample else 1.0, int(top_k or 0) if do_sample else 1,
+                                  top_p if do_sample else 1.0, seed)
+        elif do_sample and top_k != 1:
             if not (temperature > 0) or not (0 < top_p <= 1):
                 raise ValueError("temperature must be > 0 and top_p in (0, 1]")
             if seed is None:
@@ -692,7 +712,7 @@ class USDMForCausalLM:
             if past > self._vt_upto:   # K/V appended by decode steps have no V^T yet: one transposed copy over all layers
                 a0 = self._vt_upto
                 self.vtc[:, :, :, a0:past] = self.vcache[:, :, a0:past, :].transpose(2, 3)
-        segs, dev_eos = self._setup_call(input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens)
+        segs, dev_eos = self._setup_call(input_ids, past, sampling, bad_words_ids, eos_token_id, min_new_tokens, ban_mask=ban_mask)
         self._run_segs(segs)  # prefill + first token
         if sampling not in self._decodes:
             dsegs = self._build_decode(sampling)
@@ -702,7 +722,10 @@ class USDMForCausalLM:
                     merged.calls += s_.calls
                     merged.hold(*s_.keep)
                 dsegs = [merged]
-            self._decodes[sampling] = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
+            if sampling == "hook":
+                self._decodes[sampling] = GraphedSegments(dsegs, self._run_segs, enabled=False)      # host code inside: never captured
+            else:
+                self._decodes[sampling] = GraphedPlan(dsegs[0]) if (len(dsegs) == 1) else GraphedSegments(dsegs, self._run_segs)
         self._decode = self._decodes[sampling]
         eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
         produced, done, chunk = 1, False, 8
