@@ -239,57 +239,73 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(args):
-    """CPU oracle (kind 'port') on the host cores over a bounded sample; each stage extrapolated as stated."""
-    import math
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, dev):
+    """CPU oracle (kind 'port') on the host cores, as BASELINE.md section 4 states it: the FULL-size models (weights generated on the
+    GPU and copied to the host), tokenizer and BigVGAN timed in full, the 7B over a 128-token prefill + 16 decode tokens and the
+    Voicebox over 3 CFG-doubled NFEs, each scaled to the workload of one bench step.  About 30 s of CPU work."""
     from oracle import bigvgan_oracle as BO, mistral_oracle as MO, voicebox_oracle as VO, w2v_oracle as WO
+    from usdm_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
     out = {}
+    nfe = 2 * ((args.nt + 1) // 2) - 1
+    frames = (args.units * 441) // 256
     with torch.no_grad():
-        # BigVGAN: 40 frames full width -> x 861/40
+        # tokenizer, in full: 10 s of audio through all 35 layers + 10 000-centroid k-means
+        cfg = dict(WO.XLSR_1B)
+        sd = {k: v.cpu() for k, v in synth.w2v_state_dict(dev).items()}
+        cen = synth.w2v_centroids(dev).cpu()
+        wave = torch.randn(160000) * 0.1
+        t = time.time(); WO.kmeans_assign(WO.features(sd, cfg, wave, 34), cen); out["tokenizer_s"] = time.time() - t
+        del sd, cen
+        # BigVGAN, in full: 861 frames
         h = dict(BO.BIGVGAN_22K_80)
         sd = BO.random_state_dict(h, 0)
-        mel = torch.randn(1, 80, 120) * 2.1575 - 5.5419
-        t = time.time(); BO.bigvgan_forward(sd, h, mel); out["bigvgan_s"] = (time.time() - t) * 861 / 120
+        mel = torch.randn(1, 80, frames) * 2.1575 - 5.5419
+        t = time.time(); BO.bigvgan_forward(sd, h, mel); out["bigvgan_s"] = time.time() - t
         del sd
-        # Voicebox: one CFG-doubled NFE at 6 of 24 layers, S=1117 -> x4 layers, x63 NFE
-        cfg = dict(VO.VOICEBOX_CFG, num_hidden_layers=12)
+        # Voicebox: 3 CFG-doubled NFEs at full depth and length (S = 256 + frames), scaled to the step's NFE count
+        cfg = dict(VO.VOICEBOX_CFG)
         sd = VO.random_state_dict(cfg, 0)
-        S = 1117
+        S = 256 + frames
         x = torch.randint(0, 10000, (2, S)); y = torch.randn(2, 80, S)
-        t = time.time(); VO.estimator_forward(sd, cfg, x, y, y, torch.full((2, 1, 1), 0.5), torch.tensor([S, S]))
-        out["voicebox_s"] = (time.time() - t) * 2 * (2 * ((args.nt + 1) // 2) - 1)
-        del sd
-        # LLM: 1 of 32 layers at full width, bf16: prefill 128 tokens (-> x prompt tokens/128) and 3 decode steps
-        cfg = dict(MO.MISTRAL_7B_USDM, num_hidden_layers=1, vocab_size=1024)
-        sd = MO.random_state_dict(cfg, 0)
-        ids = torch.randint(0, 1024, (128,))
-        t = time.time(); _, cache = MO.forward(sd, cfg, ids); tp = time.time() - t
         t = time.time()
         for _ in range(3):
+            VO.estimator_forward(sd, cfg, x, y, y, torch.full((2, 1, 1), 0.5), torch.tensor([S, S]))
+        out["voicebox_s"] = (time.time() - t) / 3 * nfe
+        del sd
+        # 7B, all 32 layers, bf16: 128-token prefill (scaled to the three prompts) + 16 decode tokens (scaled to the generated count)
+        cfg = dict(MO.MISTRAL_7B_USDM)
+        sd = {k: v.cpu() for k, v in synth.random_llm_state_dict(cfg, dev, seed=3).items()}
+        torch.cuda.empty_cache()
+        ids = torch.randint(32002, 42002, (128,))
+        t = time.time(); _, cache = MO.forward(sd, cfg, ids); tp = time.time() - t
+        t = time.time()
+        for _ in range(16):
             _, cache = MO.forward(sd, cfg, ids[:1], cache)
-        td = (time.time() - t) / 3
-        prompt_tokens = 554 + 592 + 631
-        out["llm_s"] = 32 * (tp * prompt_tokens / 128 + td * (2 * args.text_tokens + args.units))
+        td = (time.time() - t) / 16
+        prompt_tokens = 548 + 586 + 619
+        n_gen = 2 * args.text_tokens + args.units
+        out["llm_s"] = tp * prompt_tokens / 128 + td * n_gen
+        out_tok = 1.0 / td
         del sd, cache
-        # tokenizer: conv stack on 2 s (-> x5) + 1 encoder layer at 499 frames (-> x35) + k-means on 499 frames
-        cfg = dict(WO.XLSR_1B)
-        sd = WO.random_state_dict(cfg, 0, n_layers=1)
-        t = time.time(); WO.features(sd, cfg, torch.randn(32000) * 0.1, -1); tc = (time.time() - t) * 5
-        xw = torch.randn(160000) * 0.1
-        t = time.time(); f0 = WO.features(sd, cfg, xw, 0); tl = (time.time() - t) - tc
-        cen = torch.randn(10000, 1280)
-        t = time.time(); WO.kmeans_assign(f0, cen); tk = time.time() - t
-        out["tokenizer_s"] = tc + 35 * max(tl, 0.0) + tk
     total = sum(out.values())
-    return {"value": round(9.996 / total, 5), "unit": "x real-time", "cores": cores, "kind": "port",
-            "stage_seconds_extrapolated": {k: round(v, 2) for k, v in out.items()},
-            "llm_tokens_per_s": round((2 * args.text_tokens + args.units) / out["llm_s"], 3),
-            "sample": "CPU oracle (oracle/*.py, torch CPU, all host cores): BigVGAN 120 of 861 frames; Voicebox one CFG-doubled NFE "
-                      "at 12 of 24 layers (x2 x63); Mistral one of 32 layers bf16, 128-token prefill + 3 decode steps "
-                      "(x32 layers, scaled to 1777 prompt + 564 generated tokens); XLS-R conv stack on 2 s (x5) + 1 encoder "
-                      "layer at 499 frames (x35) + k-means"}
+    return {"value": round(9.996 / total, 5), "unit": "x real-time", "cores": cores, "cpu": cpu_model(), "kind": "port",
+            "stage_seconds": {k: round(v, 2) for k, v in out.items()},
+            "llm_decode_tokens_per_s": round(out_tok, 3), "llm_tokens_per_s": round(n_gen / out["llm_s"], 3),
+            "sample": f"CPU oracle (oracle/*.py, torch CPU, {cores} threads), full-size models: XLS-R tokenizer in full (10 s, 35 layers, "
+                      f"k-means); BigVGAN in full ({frames} frames); Voicebox 3 CFG-doubled NFEs at full depth, S={256 + frames} "
+                      f"(x{nfe}/3); Mistral-7B all 32 layers bf16: 128-token prefill (x{prompt_tokens}/128) + 16 decode tokens (x{n_gen}/16)"}
 
 
 def batched_decode_rate(llm, B=4, new_tokens=96):
@@ -431,7 +447,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - informational field only, must never break the bench line
                 res["llm_batched_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args)
+            res["cpu_baseline"] = cpu_baseline(args, dev)
     elif dist_on:
         measure_gemv_roofline(pipe.llm)  # collectives inside the TP decode need every rank
     if dist_on:

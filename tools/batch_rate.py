@@ -1,7 +1,7 @@
 """Aggregate decode tokens/s of generate_batch on the random-init 7B: python tools/batch_rate.py [B] [new_tokens]."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import synth
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4

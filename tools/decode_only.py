@@ -1,7 +1,7 @@
 """Runs N decode steps of the random-init 7B on one GPU (for rocprofv3 --pmc passes over the GEMV kernel)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import synth
 
 dev = torch.device("cuda:0")

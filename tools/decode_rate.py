@@ -1,7 +1,7 @@
 """Decode tokens/s of the random-init 7B on one GPU: python tools/decode_rate.py [new_tokens] [prompt_len]."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import synth
 
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Times the non-LLM stages separately (ms): tokenizer 10 s, one Voicebox NFE (B=2, 1117 frames), BigVGAN 861 frames."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import synth
 dev = torch.device("cuda:0")
 

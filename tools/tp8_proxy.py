@@ -3,7 +3,7 @@ call overhead of a TP=8 decode step without the xGMI wire time.  Numerically mea
 import os, sys, time
 import torch
 import torch.distributed as dist
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
 from usdm_amd import synth
 

@@ -1,7 +1,7 @@
 """Runs a few Voicebox estimator evaluations at the config-4 shape (B=2 CFG, 1117 frames) for profiling."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import synth
 dev = torch.device("cuda:0")
 vb = synth.make_voicebox(dev)

@@ -45,7 +45,9 @@ __device__ unsigned long long g_gemv_trace[8192 * 8];
 // MRG: the merged-attention input form (usdm_gemv_args.mrg_*) is a separate instantiation: its 16 partial loads per thread cost
 // ~64 VGPRs, which lowered the occupancy of EVERY shape when the branch lived in the common kernel (measured: all GEMVs 20-30 %
 // slower, profiles/r02_decode_ablation.txt).
-template <int RW, bool GLU, int NWV, bool MRG = false>
+// P2P: the fused peer-to-peer all-reduce epilogue (tensor-parallel decode) is likewise its own instantiation, so the single-GPU
+// kernels carry none of it.
+template <int RW, bool GLU, int NWV, bool MRG = false, bool P2P = false>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
   constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
@@ -57,8 +59,9 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   __shared__ int si[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int skipv = a.skip ? *a.skip : 0;   // requested now, tested once the first ring is in flight (no exposed latency)
-  const unsigned p2p_epoch = a.p2p_mode ? p2p_load_epoch(a.p2p) : 0u;      // likewise: used only in the epilogue
-  const bool p2p_failed = a.p2p_mode ? p2p_load_err(a.p2p) != 0u : false;
+  unsigned p2p_epoch = 0u;      // likewise requested now, used only in the epilogue
+  bool p2p_failed = false;
+  if constexpr (P2P) { p2p_epoch = p2p_load_epoch(a.p2p); p2p_failed = p2p_load_err(a.p2p) != 0u; }
   GTR(0);
   const int K = a.K;
   const int Kpad = (K + 511) & ~511;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     }
     return;
   }
-  if (!GLU && a.p2p_mode) {
+  if constexpr (P2P && !GLU) {
     // Row-parallel projection of the tensor-parallel decode: the all-reduce of the f32 partial sums happens HERE, between the
     // workgroups that own the same rows on every rank (protocol: include/usdm_hip.h, usdm_allreduce_p2p_*).  No workgroup
     // waits for another workgroup of its own rank, so progress never depends on how much of the grid is resident.
@@ -882,10 +885,21 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   const size_t lds = (size_t)Kpad * 2;
   // Wide workgroups for the mid-size projections: one workgroup per CU with 12-16 waves stages x (and the fused
   // RMSNorm) once per 16-24 rows instead of once per 4, at the same number of loads in flight.
-  if (a.mrg_po) {   // o_proj with the attention merge in its prologue: the 7B shape (4096 outputs) or the general form
-    USDM_CHECK_ARG(!glu && !a.part_val, "usdm_gemv: merged-attention input is for plain projections");
-    if (nout % 256 == 0 && nout / 256 == 16) hipLaunchKernelGGL((gemv_kernel<1, false, 16, true>), dim3(256), dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((gemv_kernel<1, false, 4, true>), dim3(cdiv(nout, 4)), dim3(256), lds, st, a);
+  if (a.mrg_po || a.p2p_mode) {   // o_proj with the attention merge in its prologue and / or a row-parallel projection with the
+    // peer-to-peer all-reduce in its epilogue: the 4096-output shape of the 7B (one 16-wave workgroup per CU) or the general form
+    USDM_CHECK_ARG(!glu && !a.part_val, "usdm_gemv: merged-attention input / fused all-reduce are for plain projections");
+    const bool big = nout % 256 == 0 && nout / 256 == 16;
+    const dim3 gb(256), bb(1024), gs(cdiv(nout, 4)), bs(256);
+    if (a.mrg_po && a.p2p_mode) {
+      if (big) hipLaunchKernelGGL((gemv_kernel<1, false, 16, true, true>), gb, bb, lds, st, a);
+      else hipLaunchKernelGGL((gemv_kernel<1, false, 4, true, true>), gs, bs, lds, st, a);
+    } else if (a.mrg_po) {
+      if (big) hipLaunchKernelGGL((gemv_kernel<1, false, 16, true, false>), gb, bb, lds, st, a);
+      else hipLaunchKernelGGL((gemv_kernel<1, false, 4, true, false>), gs, bs, lds, st, a);
+    } else {
+      if (big) hipLaunchKernelGGL((gemv_kernel<1, false, 16, false, true>), gb, bb, lds, st, a);
+      else hipLaunchKernelGGL((gemv_kernel<1, false, 4, false, true>), gs, bs, lds, st, a);
+    }
     USDM_LAUNCH_CHECK();
     return 0;
   }

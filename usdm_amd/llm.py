@@ -93,7 +93,7 @@ class USDMForCausalLM:
         # p2p: a committed usdm_amd.p2p.P2PComm -> the decode step exchanges its partial sums peer to peer inside the GEMV
         # epilogues (p2p_fused, default) or through put + usdm_allreduce_p2p_reduce launches (split form, USDM_P2P_FUSED=0)
         self.p2p = p2p
-        import os as _os
+        _os = os
         self.p2p_fused = (_os.environ.get("USDM_P2P_FUSED", "1") == "1") if p2p_fused is None else bool(p2p_fused)
         if p2p is not None:
             if not self.tp_path:
@@ -116,7 +116,6 @@ class USDMForCausalLM:
             # the kernels here implement full causal attention, which is the same thing up to 4096 tokens and not beyond
             raise NotImplementedError(f"ctx_max {self.ctx_max} exceeds the sliding window ({c.get('sliding_window', 4096)}): "
                                       "sliding-window attention is not implemented")
-        import os
         # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
         # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
         # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
@@ -231,7 +230,6 @@ class USDMForCausalLM:
         self.vcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
         # V^T of the prompt tokens (what the prefill attention consumes), kept across generate() calls so that a prompt which
         # extends the cached sequence only prefills its new tokens (the reference's three rounds: src/inference.py:61-83)
-        import os
         # Opt-in (USDM_PREFIX_REUSE=1 or .reuse_prefix = True): cached rows written by decode steps come from the GEMV path and
         # can differ from a from-scratch prefill by a bf16 ulp, so the result is close to, not bit-identical with, the
         # reference's recompute-every-round behaviour.
@@ -451,7 +449,6 @@ class USDMForCausalLM:
         part = Z(H, dt=torch.float32) if tp > 1 else None
         # last-arriver counters of the fused partial merge (self-resetting).  Off by default: measured 11.3-11.6 us per layer
         # against 5.9 + 4.6 us for the split kernel + merge kernel (profiles/r01_decode_ablation.txt)
-        import os
         cnt = Z(Hkv, dt=torch.int32) if os.environ.get("USDM_ATTN_FUSED_MERGE", "0") == "1" else None
         # Tensor-parallel path: the residual add that follows each all-reduce is folded into the NEXT GEMV's prologue
         # (usdm_gemv x_delta / x_out) instead of a usdm_residual_add launch; the residual stream ping-pongs between two

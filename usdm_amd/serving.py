@@ -67,11 +67,13 @@ class RequestOutput:
 
 def static_mask_of(processors, vocab, device):
     """If the processors only ever write -inf into a FIXED set of ids (and leave every other logit alone), return that set as a
-    0/1 uint8 mask [vocab]; else None.  Decided by two probes with different histories and logits."""
+    0/1 uint8 mask [vocab]; else None.  Decided by probing with several histories / logit vectors (a heuristic: a processor that
+    reacts only to some particular history can pass; SamplingParams(static_logits_mask=False) forces the general path)."""
     if not processors:
         return torch.zeros(vocab, dtype=torch.uint8, device=device)
     g = torch.Generator().manual_seed(0)
-    probes = [([], torch.zeros(vocab)), ([5, 17, 3, 17], torch.randn(vocab, generator=g))]
+    hists = [[], [vocab - 1], [5, vocab // 2, 3, vocab // 2], [vocab // 3] * 9 + [vocab - 2], list(range(7, min(vocab, 39)))]
+    probes = [(h, torch.zeros(vocab) if i == 0 else torch.randn(vocab, generator=g)) for i, h in enumerate(hists)]
     masks = []
     for hist, lg in probes:
         out = lg.clone().to(device)
@@ -84,7 +86,7 @@ def static_mask_of(processors, vocab, device):
         if not torch.equal(out[~m], lg[~m]):
             return None
         masks.append(m)
-    if not torch.equal(masks[0], masks[1]):
+    if any(not torch.equal(masks[0], m) for m in masks[1:]):
         return None
     return masks[0].to(torch.uint8).to(device)
 

@@ -26,8 +26,8 @@ def _gen(dev, seed):
     return torch.Generator(device=dev).manual_seed(seed)
 
 
-def make_unit_extractor(dev, cfg=None, n_layers=35, seed=1, cseed=2):
-    """XLS-R 1B up to encoder layer 34 + 10 000 centroids, fp32, random."""
+def w2v_state_dict(dev, cfg=None, n_layers=35, seed=1):
+    """Random XLS-R weights (HF Wav2Vec2Model key names), fp32, generated on the device."""
     cfg = dict(cfg or XLSR_1B)
     g = _gen(dev, seed)
     r = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
@@ -51,8 +51,19 @@ def make_unit_extractor(dev, cfg=None, n_layers=35, seed=1, cseed=2):
             sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1 + 0.1 * r(H), 0.1 * r(H)
         sd[p + "feed_forward.intermediate_dense.weight"], sd[p + "feed_forward.intermediate_dense.bias"] = r(I, H, sc=H ** -0.5), r(I, sc=0.05)
         sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"] = r(H, I, sc=I ** -0.5), r(H, sc=0.05)
-    cen = torch.randn(cfg["n_units"], H, device=dev, generator=_gen(dev, cseed))
-    return UnitExtractor(None, None, device=dev, config=cfg, state_dict=sd, centroids=cen)
+    return sd
+
+
+def w2v_centroids(dev, cfg=None, cseed=2):
+    cfg = dict(cfg or XLSR_1B)
+    return torch.randn(cfg["n_units"], cfg["hidden_size"], device=dev, generator=_gen(dev, cseed))
+
+
+def make_unit_extractor(dev, cfg=None, n_layers=35, seed=1, cseed=2):
+    """XLS-R 1B up to encoder layer 34 + 10 000 centroids, fp32, random."""
+    cfg = dict(cfg or XLSR_1B)
+    return UnitExtractor(None, None, device=dev, config=cfg, state_dict=w2v_state_dict(dev, cfg, n_layers, seed),
+                         centroids=w2v_centroids(dev, cfg, cseed))
 
 
 def random_llm_state_dict(cfg, dev, seed=3, norm_jitter=0.1):
