@@ -244,6 +244,30 @@ typedef struct usdm_gemv_args {
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
 
+/* Chained decode GEMVs in ONE persistent launch (round 2): up to 4 consecutive projections of the decode step, each consuming
+ * the previous one's output vector (e.g. o_proj -> gate/up -> down_proj -> next layer's qkv), run by one resident grid.
+ * Between two phases there is an all-to-all dependency (every workgroup needs the whole vector), i.e. a grid barrier; it is
+ * hidden because the weights do not depend on the activations: every wave requests the first ring of its NEXT phase's weight
+ * rows before it waits, so HBM keeps streaming across the phase boundary instead of draining and ramping up again as at a
+ * launch boundary.  Per output row the arithmetic (lane partition of K, accumulation order, rounding points, RMSNorm / SwiGLU /
+ * residual fusion) is that of usdm_gemv, bit for bit.
+ *   ph[i]   : the usdm_gemv_args of phase i (plain or SwiGLU projections with y16 output; no lm_head / p2p / x_delta / merge
+ *             modes; K a multiple of 512).  x of phase i+1 is normally y16 of phase i (or the residual stream it updated).
+ *   sync    : 8 device words owned by the caller, zero-initialised once: [0] generation, [1] error, [2..4] arrival counters.
+ *             Counters are monotonic (target = (generation + 1) * workgroups), so a captured hipGraph replays correctly
+ *             without a memset node.
+ *   Every wait is bounded (timeout_ms of the 100 MHz clock): on expiry the error word is set (USDM_CHAIN_ERR_TIMEOUT) and
+ *   the kernel finishes with garbage instead of hanging; once set, later launches do not wait.  Needs all workgroups
+ *   resident (2 x 448 threads per CU on the 256 CUs: nothing else may occupy the GPU for long). */
+enum { USDM_CHAIN_MAX_PHASES = 4, USDM_CHAIN_ERR_TIMEOUT = 1 };
+typedef struct usdm_gemv_chain_args {
+  usdm_gemv_args ph[4];
+  int32_t nph;
+  uint32_t* sync;
+  int32_t timeout_ms;
+} usdm_gemv_chain_args;
+int usdm_gemv_chain(const usdm_gemv_chain_args* args, usdm_stream_t stream);
+
 /* Batched decode: the same GEMV over nb <= 4 input vectors, weights streamed once per step.
  * g holds item 0's pointers; item b is at + b * stride.  Per item the arithmetic is that of usdm_gemv, bit for bit. */
 typedef struct usdm_gemv_batch_args {

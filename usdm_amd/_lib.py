@@ -114,6 +114,10 @@ class GemvArgs(C.Structure):
     ]
 
 
+class GemvChainArgs(C.Structure):
+    _fields_ = [("ph", GemvArgs * 4), ("nph", C.c_int32), ("sync", C.c_void_p), ("timeout_ms", C.c_int32)]
+
+
 class GemvBatchArgs(C.Structure):
     _fields_ = [
         ("g", GemvArgs), ("nb", C.c_int32), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("res_bs", C.c_int64), ("part_bs", C.c_int32),
@@ -178,7 +182,7 @@ def _selfcheck():
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
                       ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs),
-                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev)):
+                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev), ("gemv_chain", GemvChainArgs)):
         n = getattr(lib, f"usdm_sizeof_{name}" if name in ("decode_state", "p2p_dev") else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

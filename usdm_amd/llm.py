@@ -252,6 +252,7 @@ class USDMForCausalLM:
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
         self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
+        self.chain_sync = torch.zeros(8, dtype=torch.int32, device=dev)   # usdm_gemv_chain: generation, error, arrival counters
         # arg-max partials: nparts slots per rank, the same on every rank (vocab_shard); slots the lm_head launch does not
         # write (last rank's shorter shard) stay "no candidate"
         nv = lambda n: torch.full((n,), float("-inf"), dtype=torch.float32, device=dev)
@@ -463,6 +464,24 @@ class USDMForCausalLM:
 
         skp = self.st_done   # decode kernels return at once after a device-side EOS (see _alloc)
 
+        if tp == 1 and self.chain in (3, 4) and cnt is None and not self.merge_in_oproj:
+            G = lambda *a_, **k_: ops.gemv(*a_, skip=skp, only_args=True, **k_)
+            for l in range(L):
+                w = self.W["layers"][l]
+                if l == 0 or self.chain == 3:
+                    ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
+                ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
+                                ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, plan=plan)
+                ph = [G(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h),
+                      G(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act),
+                      G(w["down"], act, N=H, K=I, residual=h, y16=h)]
+                if self.chain == 4 and l + 1 < L:
+                    w2 = self.W["layers"][l + 1]
+                    ph.append(G(w2["qkv"], h, N=nq, K=H, norm_w=w2["ln1"], eps=c["rms_norm_eps"], y16=qkv))
+                ops.gemv_chain(ph, self.chain_sync, plan=plan)
+            self._lm_head_and_pick(plan, h, True, segs, sampling, skip=skp)
+            segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
+            return segs
         for l in range(L):   # h already holds the embedding of the current token (written by usdm_argmax_final)
             w = self.W["layers"][l]
             if pend is not None:
@@ -733,6 +752,9 @@ class USDMForCausalLM:
             toks = self.st_out[:produced].tolist()  # host sync point (EOS check)
             if self.p2p is not None:
                 self.p2p.raise_if_failed()          # a peer that never delivered surfaces here, not as a hang
+            if self.chain and int(self.chain_sync[1].item()):
+                raise RuntimeError("usdm_gemv_chain: a grid barrier timed out (the persistent decode kernel was not fully resident); "
+                                   "results are invalid - rerun with USDM_GEMV_CHAIN=0")
             hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
             if hit:
                 toks = toks[:hit[0] + 1]

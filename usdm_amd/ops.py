@@ -209,8 +209,9 @@ def process_unit(units, rep, hop):
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
          ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, p2p=None, p2p_site=0,
-         p2p_mode=0, merge=None, plan=None):
-    """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h).  p2p: a usdm_amd.p2p.P2PComm (fused all-reduce)."""
+         p2p_mode=0, merge=None, plan=None, only_args=False):
+    """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h).  p2p: a usdm_amd.p2p.P2PComm (fused all-reduce).
+    only_args=True: return the filled usdm_gemv_args instead of launching (a phase of usdm_gemv_chain)."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out, skip)
     if x_out is not None and x_out.data_ptr() == x.data_ptr():
         raise ValueError("usdm_gemv: x_out must not alias x")
@@ -228,7 +229,22 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     if p2p is not None and p2p_mode:
         p2p.check_site(p2p_site, N)
         a.p2p, a.p2p_site, a.p2p_mode = p2p.dev_ptr, p2p_site, p2p_mode
+    if only_args:
+        return a
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
+
+
+def gemv_chain(phases, sync, timeout_ms=2000, plan=None):
+    """usdm_gemv_chain: up to 4 consecutive decode projections in one persistent launch.  phases: usdm_gemv_args from
+    gemv(..., only_args=True); sync: int32/uint32 device tensor of >= 8 words, zero-initialised once by the caller."""
+    _need_cuda(sync)
+    if not (1 <= len(phases) <= 4) or sync.numel() < 8 or sync.element_size() != 4:
+        raise ValueError("gemv_chain: 1..4 phases and an 8-word sync block")
+    c = _lib.GemvChainArgs()
+    for i, ph in enumerate(phases):
+        c.ph[i] = ph
+    c.nph, c.sync, c.timeout_ms = len(phases), _ptr(sync), timeout_ms
+    _go(plan, "usdm_gemv_chain", lib.usdm_gemv_chain, C_.byref(c))
 
 
 def p2p_reduce(p2p, site, n, h, skip=None, plan=None):
