@@ -252,7 +252,9 @@ class USDMForCausalLM:
         self.ban_all_off = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)
         self.ban = torch.zeros(self.v1 - self.v0, dtype=torch.uint8, device=dev)  # live mask read by the graphs
         self.h_dec = torch.zeros(c["hidden_size"], dtype=bf, device=dev)  # residual stream of the decode step
-        self.chain_sync = torch.zeros(8, dtype=torch.int32, device=dev)   # usdm_gemv_chain: generation, error, arrival counters
+        # usdm_gemv_chain sync blocks (generation, error, arrival counters): ONE PER CHAIN PATTERN - the counters of a block are
+        # monotonic in lockstep with its generation, so launches with different phase counts must not share a block
+        self.chain_sync = torch.zeros(2, 8, dtype=torch.int32, device=dev)
         # arg-max partials: nparts slots per rank, the same on every rank (vocab_shard); slots the lm_head launch does not
         # write (last rank's shorter shard) stay "no candidate"
         nv = lambda n: torch.full((n,), float("-inf"), dtype=torch.float32, device=dev)
@@ -478,7 +480,7 @@ class USDMForCausalLM:
                 if self.chain == 4 and l + 1 < L:
                     w2 = self.W["layers"][l + 1]
                     ph.append(G(w2["qkv"], h, N=nq, K=H, norm_w=w2["ln1"], eps=c["rms_norm_eps"], y16=qkv))
-                ops.gemv_chain(ph, self.chain_sync, plan=plan)
+                ops.gemv_chain(ph, self.chain_sync[0 if len(ph) == self.chain else 1], plan=plan)
             self._lm_head_and_pick(plan, h, True, segs, sampling, skip=skp)
             segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
             return segs
@@ -752,7 +754,7 @@ class USDMForCausalLM:
             toks = self.st_out[:produced].tolist()  # host sync point (EOS check)
             if self.p2p is not None:
                 self.p2p.raise_if_failed()          # a peer that never delivered surfaces here, not as a hang
-            if self.chain and int(self.chain_sync[1].item()):
+            if self.chain and int(self.chain_sync[:, 1].sum().item()):
                 raise RuntimeError("usdm_gemv_chain: a grid barrier timed out (the persistent decode kernel was not fully resident); "
                                    "results are invalid - rerun with USDM_GEMV_CHAIN=0")
             hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
