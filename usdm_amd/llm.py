@@ -129,6 +129,16 @@ class USDMForCausalLM:
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
         if self.NS == 1:
             self.merge_in_oproj = False          # one workgroup per kv head: nothing to merge
+        # Chained decode GEMVs (usdm_gemv_chain): consecutive projections of a layer in ONE persistent launch whose weight stream
+        # runs across the phase boundaries.  0 = off (one launch per projection; the DEFAULT: measured slower, see below),
+        # 3 = o_proj -> gate/up -> down_proj, 4 = ... -> the next layer's qkv as well.  Single-GPU path only (the kernel needs the
+        # whole GPU resident).  Measured (profiles/r02_decode_ablation.txt section 3): 85 vs 69 us per layer for 3 phases - a flat
+        # counter grid barrier at 2 workgroups per CU costs ~13 us, more than the launch boundary + ramp it replaces, and one
+        # workgroup shape for every phase streams 10-25 % slower than the per-shape tuned kernels.
+        self.chain = int(os.environ.get("USDM_GEMV_CHAIN", "0"))
+        if self.tp_path or c["hidden_size"] < 4096:
+            self.chain = 0
+        self.chain_sync = None
         self.W = None
         # bounded caches (plancache.LRU): prefill plans are keyed by exact prompt length (a plan is argument structs + ~60 KB of
         # workspace per token; no hipGraph), decode plans / graphs by {greedy, sampling} only
