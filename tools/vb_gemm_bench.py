@@ -3,7 +3,7 @@
 USDM_GEMM_TILE overrides the tile for the whole process."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from usdm_amd import ops
 from usdm_amd.graph import GraphedPlan
 dev = torch.device("cuda:0")

@@ -745,6 +745,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 9) return launch<bf16_t, 128, 128, 2, 2, true, 4, 1>(a, st);
     if (sel == 10) return launch<bf16_t, 128, 64, 2, 2, true, 3, 2>(a, st);
     if (sel == 11) return launch<bf16_t, 128, 128, 2, 2, true, 3, 2>(a, st);
+    // (256x128 / 128x256 tiles were measured in round 2 and are not instantiated: profiles/r02_gemm_ablation.txt)
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
