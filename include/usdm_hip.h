@@ -265,8 +265,22 @@ typedef struct usdm_gemv_chain_args {
   int32_t nph;
   uint32_t* sync;
   int32_t timeout_ms;
+  uint64_t* gran;   /* usdm_gemv_engine only: 3 x 8192 eight-byte granules of hand-off space (192 KB), any content */
+  int32_t norm_nth[4]; /* filled by the launcher: threads per workgroup of the usdm_gemv variant each phase would run with */
 } usdm_gemv_chain_args;
 int usdm_gemv_chain(const usdm_gemv_chain_args* args, usdm_stream_t stream);
+
+/* The same chain on a loader / consumer ENGINE (round 2, second form): one 4-wave workgroup per CU; wave 0 only streams the
+ * CU's share of every phase's weight rows into a 7 x 16 KiB LDS ring by LDS-DMA (buffer_load ... lds, non-temporal), running
+ * ahead across phase boundaries as far as the ring allows; waves 1-3 take ring slots (FULL / FREE words in LDS), multiply
+ * against the phase's input vector held in LDS and publish each output pair twice: as plain bf16 (for later launches) and as
+ * an 8-byte granule {tag = epoch, 2 x bf16} that every CU's gathering wave sweeps into its LDS copy of the next phase's input
+ * (the data is its own flag: no grid barrier, no counter).  Per row the arithmetic - lane partition of K, accumulation order,
+ * RMSNorm partial-sum order of the equivalent usdm_gemv launch, rounding points - is that of usdm_gemv, bit for bit.
+ * Shapes: every phase's output count a multiple of 512; K = 4096 (any phase) or 16 < K/512 <= 32 with K/512 even (plain
+ * phases, e.g. 14336).  sync: as usdm_gemv_chain ([0] generation, [1] error); all waits bounded. */
+int usdm_gemv_engine(const usdm_gemv_chain_args* args, usdm_stream_t stream);
+int usdm_gemv_threads(const usdm_gemv_args* args);   /* threads per workgroup usdm_gemv would launch this projection with */
 
 /* Batched decode: the same GEMV over nb <= 4 input vectors, weights streamed once per step.
  * g holds item 0's pointers; item b is at + b * stride.  Per item the arithmetic is that of usdm_gemv, bit for bit. */

@@ -103,3 +103,62 @@ def test_generation_with_chained_decode_is_token_identical(dev):
             assert any(w == "usdm_gemv_chain" for w, _, _ in m._decode.plan.calls)
             assert int(m.chain_sync[:, 1].sum().item()) == 0
     assert outs["3"] == outs["0"] and outs["4"] == outs["0"]
+
+
+@pytest.mark.parametrize("nph", [1, 2, 3, 4])
+def test_engine_bit_identical_to_separate_launches(dev, nph):
+    """usdm_gemv_engine (LDS-DMA loader + consumer waves per CU, granule hand-offs between phases) vs one usdm_gemv launch per
+    projection at the 7B shapes: bit-identical vectors, also when replayed as a hipGraph (generation-tagged granules)."""
+    from usdm_amd import ops
+    from usdm_amd.graph import GraphedPlan
+    W, x, dims = _setup(dev)
+    H, I, NQ = dims
+    bf = torch.bfloat16
+    mk = lambda: (x["h"].clone(), x["ao"].clone(), torch.zeros(I, dtype=bf, device=dev), torch.zeros(NQ, dtype=bf, device=dev))
+    h, ao, act, qkv = mk()
+    for f in _phases(ops, W, h, ao, act, qkv, dims, nph):
+        f()
+    ref = (h.clone(), act.clone(), qkv.clone())
+    sync = torch.zeros(8, dtype=torch.int32, device=dev)
+    gran = torch.zeros(3 * 8192, dtype=torch.int64, device=dev)
+    h2, ao2, act2, qkv2 = mk()
+    plan = ops.Plan()
+    ops.gemv_engine([f(only_args=True) for f in _phases(ops, W, h2, ao2, act2, qkv2, dims, nph)], sync, gran, timeout_ms=500, plan=plan)
+
+    def check(tag):
+        torch.cuda.synchronize()
+        assert int(sync[1].item()) == 0, f"{tag}: engine wait timed out"
+        assert torch.equal(h2, ref[0]), f"{tag}: residual stream differs: {(h2 != ref[0]).sum().item()} of {H}"
+        if nph >= 2:
+            assert torch.equal(act2, ref[1]), f"{tag}: SwiGLU output differs: {(act2 != ref[1]).sum().item()} of {I}"
+        if nph >= 4:
+            assert torch.equal(qkv2, ref[2]), f"{tag}: qkv differs: {(qkv2 != ref[2]).sum().item()} of {NQ}"
+    plan.run()
+    check("eager")
+    gp = GraphedPlan(plan)
+    for rep in range(4):
+        h2.copy_(x["h"]); act2.zero_(); qkv2.zero_()
+        gp.run()
+        check(f"replay {rep}")
+    assert int(sync[0].item()) == (5 if nph > 1 else 0)
+
+
+def test_generation_with_engine_decode_is_token_identical(dev):
+    from oracle import mistral_oracle as MO
+    from usdm_amd import synth
+    from usdm_amd.llm import USDMForCausalLM
+    cfg = dict(MO.MISTRAL_7B_USDM, num_hidden_layers=4)
+    sd = synth.random_llm_state_dict(cfg, dev, seed=13)
+    ids = torch.randint(32002, 42002, (1, 50), generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = {}
+    for mode in ("0", "e3", "e4"):
+        os.environ["USDM_GEMV_CHAIN"] = mode
+        try:
+            m = USDMForCausalLM.from_state_dict(sd, cfg, dev, ctx_max=128)
+        finally:
+            os.environ.pop("USDM_GEMV_CHAIN")
+        outs[mode] = m.generate(input_ids=ids, max_new_tokens=24)[0].tolist()
+        if mode != "0":
+            assert any(w == "usdm_gemv_engine" for w, _, _ in m._decode.plan.calls)
+            assert int(m.chain_sync[:, 1].sum().item()) == 0
+    assert outs["e3"] == outs["0"] and outs["e4"] == outs["0"]

@@ -15,6 +15,7 @@ Ws = [dict(o=r(H, H, sc=H ** -0.5), gu=_pack_gate_up(r(I, H, sc=H ** -0.5), r(I,
            ln=torch.ones(H, device=dev)) for _ in range(NL)]
 h, ao, act, qkv = r(H, sc=1.0), r(H, sc=1.0), torch.zeros(I, dtype=bf, device=dev), torch.zeros(NQ, dtype=bf, device=dev)
 sync = torch.zeros(8, dtype=torch.int32, device=dev)
+gran = torch.zeros(3 * 8192, dtype=torch.int64, device=dev)
 
 
 def phases(W, which, **k):
@@ -38,12 +39,16 @@ def timeit(plan, n=10):
 
 
 for which in (["o"], ["gu"], ["down"], ["qkv"], ["gu", "down"], ["o", "gu", "down"], ["o", "gu", "down", "qkv"]):
-    sep, ch = ops.Plan(), ops.Plan()
+    sep, ch, en = ops.Plan(), ops.Plan(), ops.Plan()
+    sync.zero_()          # one block per pattern (the counters are monotonic in lockstep with the generation)
+    sync2 = torch.zeros(8, dtype=torch.int32, device=dev)
     for W in Ws:
         phases(W, which, plan=sep)
         ops.gemv_chain(phases(W, which, only_args=True), sync, plan=ch)
+        ops.gemv_engine(phases(W, which, only_args=True), sync2, gran, timeout_ms=500, plan=en)
     try:
-        t_sep, t_ch = timeit(sep), timeit(ch)
-        print(f"{'+'.join(which):16s} separate {t_sep:7.2f} us   chain {t_ch:7.2f} us   (per layer, cold weights)   err={int(sync[1])}", flush=True)
+        t_sep, t_ch, t_en = timeit(sep), timeit(ch), timeit(en)
+        print(f"{'+'.join(which):16s} separate {t_sep:7.2f} us   chain {t_ch:7.2f} us   engine {t_en:7.2f} us   (per layer, cold weights)   "
+              f"err={int(sync[1])}/{int(sync2[1])}", flush=True)
     except Exception as e:
         print(which, "failed:", e, flush=True)

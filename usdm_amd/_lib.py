@@ -115,7 +115,8 @@ class GemvArgs(C.Structure):
 
 
 class GemvChainArgs(C.Structure):
-    _fields_ = [("ph", GemvArgs * 4), ("nph", C.c_int32), ("sync", C.c_void_p), ("timeout_ms", C.c_int32)]
+    _fields_ = [("ph", GemvArgs * 4), ("nph", C.c_int32), ("sync", C.c_void_p), ("timeout_ms", C.c_int32), ("gran", C.c_void_p),
+                ("norm_nth", C.c_int32 * 4)]
 
 
 class GemvBatchArgs(C.Structure):

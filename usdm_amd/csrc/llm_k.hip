@@ -947,6 +947,22 @@ extern "C" int usdm_dbg_gemv_trace(unsigned long long* host, int n) {
 
 extern "C" int usdm_gemv_nblocks(int32_t N, int32_t act) { return cdiv(N, 16); }
 
+// threads per workgroup of the variant usdm_gemv picks for this projection (the fused RMSNorm's partial sums follow that
+// partition; usdm_gemv_engine reproduces it to stay bit-identical).  Keep in step with usdm_gemv below.
+extern "C" int usdm_gemv_threads(const usdm_gemv_args* pa) {
+  const usdm_gemv_args& a = *pa;
+  const bool glu = a.act == USDM_ACT_SWIGLU;
+  const int nout = glu ? a.N / 2 : a.N;
+  if (a.mrg_po || a.p2p_mode) return (nout % 256 == 0 && nout / 256 == 16) ? 1024 : 256;
+  if (!glu && !a.part_val && nout % 256 == 0) {
+    if (nout / 256 == 16) return 1024;
+    if (nout / 256 == 24) return 768;
+  }
+  static const int glu7 = getenv("USDM_GEMV_GLU7") ? atoi(getenv("USDM_GEMV_GLU7")) : 1;
+  if (glu && glu7 && nout % 14 == 0 && (nout / 14) % 512 == 0) return 448;
+  return 256;
+}
+
 extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
                                  const usdm_decode_state* st, const void* embed_table, int32_t Hd, void* h_out,
                                  usdm_stream_t stream) {

@@ -135,8 +135,11 @@ class USDMForCausalLM:
         # whole GPU resident).  Measured (profiles/r02_decode_ablation.txt section 3): 85 vs 69 us per layer for 3 phases - a flat
         # counter grid barrier at 2 workgroups per CU costs ~13 us, more than the launch boundary + ramp it replaces, and one
         # workgroup shape for every phase streams 10-25 % slower than the per-shape tuned kernels.
-        self.chain = int(os.environ.get("USDM_GEMV_CHAIN", "0"))
-        if self.tp_path or c["hidden_size"] < 4096:
+        # "e3" / "e4": the same chains on the loader / consumer engine (usdm_gemv_engine: LDS-DMA weight ring, granule hand-offs).
+        mode = os.environ.get("USDM_GEMV_CHAIN", "0")
+        self.chain_engine = mode.startswith("e")
+        self.chain = int(mode.lstrip("e") or 0)
+        if self.tp_path or c["hidden_size"] != 4096:
             self.chain = 0
         self.chain_sync = None
         self.W = None
@@ -265,6 +268,7 @@ class USDMForCausalLM:
         # usdm_gemv_chain sync blocks (generation, error, arrival counters): ONE PER CHAIN PATTERN - the counters of a block are
         # monotonic in lockstep with its generation, so launches with different phase counts must not share a block
         self.chain_sync = torch.zeros(2, 8, dtype=torch.int32, device=dev)
+        self.chain_gran = torch.zeros(3 * 8192, dtype=torch.int64, device=dev)     # usdm_gemv_engine hand-off granules
         # arg-max partials: nparts slots per rank, the same on every rank (vocab_shard); slots the lm_head launch does not
         # write (last rank's shorter shard) stay "no candidate"
         nv = lambda n: torch.full((n,), float("-inf"), dtype=torch.float32, device=dev)
@@ -490,7 +494,11 @@ class USDMForCausalLM:
                 if self.chain == 4 and l + 1 < L:
                     w2 = self.W["layers"][l + 1]
                     ph.append(G(w2["qkv"], h, N=nq, K=H, norm_w=w2["ln1"], eps=c["rms_norm_eps"], y16=qkv))
-                ops.gemv_chain(ph, self.chain_sync[0 if len(ph) == self.chain else 1], plan=plan)
+                sync = self.chain_sync[0 if len(ph) == self.chain else 1]
+                if self.chain_engine:
+                    ops.gemv_engine(ph, sync, self.chain_gran, plan=plan)
+                else:
+                    ops.gemv_chain(ph, sync, plan=plan)
             self._lm_head_and_pick(plan, h, True, segs, sampling, skip=skp)
             segs[0].hold(*[t for s in segs if isinstance(s, ops.Plan) for t in s.keep])
             return segs

@@ -234,6 +234,19 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
     _go(plan, "usdm_gemv", lib.usdm_gemv, C_.byref(a))
 
 
+def gemv_engine(phases, sync, gran, timeout_ms=2000, plan=None):
+    """usdm_gemv_engine: the chained projections on the loader / consumer engine (LDS-DMA weight ring, granule hand-offs).
+    gran: >= 24576 int64 words of device scratch."""
+    _need_cuda(sync, gran)
+    if not (1 <= len(phases) <= 4) or sync.numel() < 8 or sync.element_size() != 4 or gran.numel() * gran.element_size() < 3 * 8192 * 8:
+        raise ValueError("gemv_engine: 1..4 phases, an 8-word sync block and 192 KB of granule space")
+    c = _lib.GemvChainArgs()
+    for i, ph in enumerate(phases):
+        c.ph[i] = ph
+    c.nph, c.sync, c.timeout_ms, c.gran = len(phases), _ptr(sync), timeout_ms, _ptr(gran)
+    _go(plan, "usdm_gemv_engine", lib.usdm_gemv_engine, C_.byref(c))
+
+
 def gemv_chain(phases, sync, timeout_ms=2000, plan=None):
     """usdm_gemv_chain: up to 4 consecutive decode projections in one persistent launch.  phases: usdm_gemv_args from
     gemv(..., only_args=True); sync: int32/uint32 device tensor of >= 8 words, zero-initialised once by the caller."""
