@@ -23,8 +23,8 @@
 namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 constexpr int NSLOT = 7, SLOTB = 16384;
-constexpr int XR0 = NSLOT * SLOTB, XR1 = XR0 + 8192, XR2 = XR1 + 8192;   // input-vector regions: 8 KB, 8 KB, 32 KB
-constexpr int CTL = XR2 + 32768;                                         // control words + CU-local residual values
+constexpr int XR0 = NSLOT * SLOTB, XR1 = XR0 + 8192, XR2 = XR1 + 8192;   // input-vector regions: 8 KB, 8 KB, 28 KB
+constexpr int CTL = XR2 + 28672;                                         // control words + CU-local residual values
 constexpr int ELDS = CTL + 1024;                                         // 160768 bytes
 constexpr int NCU = 256;
 // control word indices (unsigned, in LDS)
@@ -161,27 +161,24 @@ __device__ __forceinline__ void gather(const usdm_gemv_chain_args& c, int p, int
     const int ng = K / 2;
     for (int base = 0; base < ng; base += 64 * 16) {   // 16 granules per lane and pass (8 KB)
       unsigned long long v[16];
-      bool ok[16];
+      unsigned okm = 0;       // bit k: granule k of this lane has arrived (a bit mask: a bool array here gets promoted to LDS)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) ok[k] = failed || (base + k * 64 + lane >= ng);
+      for (int k = 0; k < 16; ++k)
+        if (failed || (base + k * 64 + lane >= ng)) okm |= 1u << k;
       const unsigned long long t0 = wall_clock64();
       for (unsigned spins = 0;; ++spins) {
-        bool all = true;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          if (!ok[k]) v[k] = __hip_atomic_load(g + base + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(okm & (1u << k))) v[k] = __hip_atomic_load(g + base + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          if (!ok[k]) {
-            if ((unsigned)(v[k] >> 32) == epoch_src) {
-              ok[k] = true;
-              *(unsigned*)(xs + 2 * (base + k * 64 + lane)) = (unsigned)v[k];     // one ds_write_b32 per granule
-            } else {
-              all = false;
-            }
+          if (!(okm & (1u << k)) && (unsigned)(v[k] >> 32) == epoch_src) {
+            okm |= 1u << k;
+            *(unsigned*)(xs + 2 * (base + k * 64 + lane)) = (unsigned)v[k];     // one ds_write_b32 per granule
           }
         }
+        const bool all = okm == 0xffffu;
         if (__all(all)) break;
         if ((spins & 15) == 15 && (lds_ld(ctl + W_ABORT) || wall_clock64() - t0 > tmo)) {
           if (lane == 0) {
@@ -348,7 +345,7 @@ __device__ __forceinline__ void consumer(const usdm_gemv_chain_args& c, char* sm
 }
 
 __global__ __launch_bounds__(256) void gemv_engine_kernel(const usdm_gemv_chain_args c) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ __attribute__((aligned(16))) char smem[ELDS];   // (static: the >64 KiB dynamic-LDS attribute is refused for this kernel)
   lds_u32* ctl = (lds_u32*)(__attribute__((address_space(3))) char*)(smem + CTL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int skipv = c.ph[0].skip ? *c.ph[0].skip : 0;
@@ -376,8 +373,8 @@ extern "C" int usdm_gemv_engine(const usdm_gemv_chain_args* pc, usdm_stream_t st
     const int nout = glu ? a.N / 2 : a.N, nit = a.K / 512;
     USDM_CHECK_ARG(a.W && a.x && a.y16 && a.N > 0, "usdm_gemv_engine: phase %d needs W, x and a bf16 output", p);
     USDM_CHECK_ARG(a.act == USDM_ACT_NONE || glu, "usdm_gemv_engine: phase %d: activation", p);
-    USDM_CHECK_ARG(a.K % 512 == 0 && (nit == 8 || (!glu && nit > 16 && nit <= 32 && nit % 2 == 0)) && a.ldw % 8 == 0 && a.ldw >= a.K,
-                   "usdm_gemv_engine: phase %d: K must be 4096, or (plain) an even multiple of 512 in (8192, 16384]", p);
+    USDM_CHECK_ARG(a.K % 512 == 0 && (nit == 8 || (!glu && nit > 16 && nit <= 28 && nit % 2 == 0)) && a.ldw % 8 == 0 && a.ldw >= a.K,
+                   "usdm_gemv_engine: phase %d: K must be 4096, or (plain) an even multiple of 512 in (8192, 14336]", p);
     USDM_CHECK_ARG(nout % 512 == 0 && nout <= 16384 && (!glu || (a.N % 32 == 0 && !a.residual)), "usdm_gemv_engine: phase %d: outputs must be a multiple of 512 (<= 16384)", p);
     USDM_CHECK_ARG((int64_t)a.N * a.ldw * 2 < 0xFFFFFF00ll, "usdm_gemv_engine: phase %d: weight matrix exceeds the buffer range", p);
     USDM_CHECK_ARG(!a.part_val && !a.ban && !a.y32 && !a.x_delta && !a.x_out && !a.p2p_mode && !a.mrg_po,
@@ -397,12 +394,7 @@ extern "C" int usdm_gemv_engine(const usdm_gemv_chain_args* pc, usdm_stream_t st
   }
   usdm_gemv_chain_args c = *pc;
   for (int p = 0; p < c.nph; ++p) c.norm_nth[p] = usdm_gemv_threads(&c.ph[p]);
-  static bool attr = false;
-  if (!attr) {
-    USDM_HIP(hipFuncSetAttribute((const void*)gemv_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ELDS));
-    attr = true;
-  }
-  hipLaunchKernelGGL(gemv_engine_kernel, dim3(NCU), dim3(256), ELDS, (hipStream_t)stream, c);
+  hipLaunchKernelGGL(gemv_engine_kernel, dim3(NCU), dim3(256), 0, (hipStream_t)stream, c);
   USDM_LAUNCH_CHECK();
   return 0;
 }
