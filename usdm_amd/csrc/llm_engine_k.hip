@@ -1,17 +1,18 @@
 // Loader / consumer engine for chained decode projections (include/usdm_hip.h, usdm_gemv_engine).
 //
-// One 4-wave workgroup per CU (256 workgroups, 157 KB of LDS each, so exactly one is resident per CU):
-//   wave 0 (LOADER)     streams this CU's share of every phase's weight rows, in order, into a ring of 7 x 16 KiB LDS slots by
+// One 8-wave workgroup per CU (256 workgroups, 157 KB of LDS each, so exactly one is resident per CU); NL loader waves and NC
+// consumer waves (4 + 4):
+//   LOADER wave l       owns the stream slots s = l (mod NL); it streams this CU's share of every phase's weight rows, in order, into a ring of 7 x 16 KiB LDS slots by
 //                       LDS-DMA (buffer_load_dwordx4 ... lds, non-temporal: every byte is read once by one CU).  It keeps two
 //                       slots in flight behind a counted s_waitcnt vmcnt and publishes a slot (FULL word in LDS) once its DMAs
 //                       have landed.  It never looks at activations, so it runs ahead across phase boundaries as far as the ring
 //                       allows: HBM keeps streaming while the consumers wait for the previous phase's vector.
-//   waves 1-3 (CONSUMERS) take jobs round-robin.  A job is the ring slots of one output PAIR (2 plain rows = 1 slot at K = 4096,
+//   CONSUMER waves      take jobs round-robin.  A job is the ring slots of one output PAIR (2 plain rows = 1 slot at K = 4096,
 //                       2 x (gate, up) = 2 slots for SwiGLU, 2 rows = 4 slots at K = 14336); each slot is multiplied against the
 //                       phase's input vector in LDS as soon as it is FULL and handed back (FREE word) once its bytes are in
 //                       registers.  The pair is published as plain bf16 (for later launches) and as ONE 8-byte granule
 //                       {tag = epoch, 2 x bf16} - a single aligned agent-scope store, the data is its own flag.
-//   wave 1 also GATHERS: before its first job of a phase it sweeps the previous phase's granules from all CUs into this CU's LDS
+//   the first consumer also GATHERS: before its first job of a phase it sweeps the previous phase's granules from all CUs into this CU's LDS
 //                       copy of the input vector (re-reading granules whose tag is not the epoch yet, bounded), applies the fused
 //                       RMSNorm, and sets the phase's READY word.
 // Nothing in here is a grid barrier; all inter-workgroup traffic is granules, all intra-workgroup hand-offs are LDS words.
@@ -27,6 +28,17 @@ constexpr int XR0 = NSLOT * SLOTB, XR1 = XR0 + 8192, XR2 = XR1 + 8192;   // inpu
 constexpr int CTL = XR2 + 28672;                                         // control words + CU-local residual values
 constexpr int ELDS = CTL + 1024;                                         // 160768 bytes
 constexpr int NCU = 256;
+#ifndef USDM_ENG_NL
+#define USDM_ENG_NL 4   // measured best split of 8 waves (profiles/r02_decode_ablation.txt section 4)
+#endif
+#ifndef USDM_ENG_NC
+#define USDM_ENG_NC 4
+#endif
+constexpr int NL = USDM_ENG_NL, NC = USDM_ENG_NC;   // loader waves (stream slot s belongs to loader s % NL) and consumer waves
+// own slots a loader may leave in flight behind the one it publishes; every loader holds at most LDEPTH + 1 unpublished ring slots
+// and NL * (LDEPTH + 1) must not exceed the ring (a loader waiting for a FREE slot that another loader has not published yet
+// would otherwise wait for ever)
+constexpr int LDEPTH = (NL * 3 <= 7) ? 2 : ((NL * 2 <= 7) ? 1 : 0);
 // control word indices (unsigned, in LDS)
 constexpr int W_FULL = 0, W_FREE = 8, W_READY = 16, W_ABORT = 24, W_HLOC = 32;   // hloc: 64 floats from word 32
 
@@ -81,21 +93,32 @@ __device__ __forceinline__ bool lds_wait(lds_u32* ctl, unsigned* gerr, unsigned 
   }
 }
 
-__device__ __forceinline__ void vm_wait(int n) {   // s_waitcnt vmcnt(n), n uniform in [0, 32]
+__device__ __forceinline__ void vm_wait(int n) {   // s_waitcnt vmcnt(n), n uniform in [0, 48]
   switch (n) {
 #define VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     VMC(0) VMC(1) VMC(2) VMC(3) VMC(4) VMC(5) VMC(6) VMC(7) VMC(8) VMC(9) VMC(10) VMC(11) VMC(12) VMC(13) VMC(14) VMC(15) VMC(16)
     VMC(17) VMC(18) VMC(19) VMC(20) VMC(21) VMC(22) VMC(23) VMC(24) VMC(25) VMC(26) VMC(27) VMC(28) VMC(29) VMC(30) VMC(31) VMC(32)
+    VMC(33) VMC(34) VMC(35) VMC(36) VMC(37) VMC(38) VMC(39) VMC(40) VMC(41) VMC(42) VMC(43) VMC(44) VMC(45) VMC(46) VMC(47) VMC(48)
 #undef VMC
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
+#ifdef USDM_ENG_TRACE
+__device__ unsigned long long g_eng_trace[64];
+#define ETR_T0() const unsigned long long etr_t0 = clock64()
+#define ETR_ADD(i) do { if (blockIdx.x == 0 && lane == 0) g_eng_trace[i] += clock64() - etr_t0; } while (0)
+#else
+#define ETR_T0() do { } while (0)
+#define ETR_ADD(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------- loader
-__device__ __forceinline__ void loader(const usdm_gemv_chain_args& c, char* smem, lds_u32* ctl, unsigned long long tmo, int lane) {
+__device__ __forceinline__ void loader(const usdm_gemv_chain_args& c, char* smem, lds_u32* ctl, unsigned long long tmo, int lw, int lane) {
   const int cu = blockIdx.x;
   int s = 0;                 // stream slot counter of this CU over all phases
-  int pend1 = 0, pend2 = 0;  // pieces of the two youngest issued slots (s-1, s-2 relative to the next issue)
+  int pend1 = 0, pend2 = 0;  // pieces of this loader's two youngest issued slots
+  int mine1 = -1, mine2 = -1, mine3 = -1;   // this loader's three youngest issued stream slots (newest first)
   int xsmall = 0;
   for (int p = 0; p < c.nph; ++p) {
     const usdm_gemv_args& a = c.ph[p];
@@ -104,12 +127,16 @@ __device__ __forceinline__ void loader(const usdm_gemv_chain_args& c, char* smem
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, 0xFFFFFF00u, 0x00020000);
     const unsigned ldwb = (unsigned)(a.ldw * 2);
     for (int js = 0; js < ph.nslots; ++js, ++s) {
+      if (s % NL != lw) continue;
       const int i = s % NSLOT;
       // the ring slot must have been handed back by its consumer (stream slot s - NSLOT)
       if (s >= NSLOT) {
         const unsigned need = (unsigned)(s - NSLOT + 1);
+        ETR_T0();
         if (!lds_wait(ctl, c.sync + 1, tmo, [&]() { return lds_ld(ctl + W_FREE + i) >= need; })) return;
+        ETR_ADD(lw * 4 + 0);          // loader: waiting for a free ring slot
       }
+      ETR_T0();
       // rows of this slot
       unsigned r0, r1 = 0;
       int it0 = 0;
@@ -134,17 +161,27 @@ __device__ __forceinline__ void loader(const usdm_gemv_chain_args& c, char* smem
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, off, 0, 0, 2 /* nt */);
         }
       }
-      // publish stream slot s-2 (everything but the two youngest slots has landed)
-      if (s >= 2) {
-        vm_wait(ph.pps + pend1);
-        if (lane == 0) ctl[W_FULL + (s - 2) % NSLOT] = (unsigned)(s - 1);
+      ETR_ADD(lw * 4 + 1);            // loader: address arithmetic + DMA issue
+      // publish the slot LDEPTH issues back: everything of this loader's own but its LDEPTH youngest slots has landed
+      {
+        ETR_T0();
+        if (LDEPTH == 0) {
+          vm_wait(0);
+          if (lane == 0) ctl[W_FULL + i] = (unsigned)(s + 1);
+        } else if (LDEPTH == 1) {
+          if (mine1 >= 0) { vm_wait(ph.pps); if (lane == 0) ctl[W_FULL + mine1 % NSLOT] = (unsigned)(mine1 + 1); }
+        } else {
+          if (mine2 >= 0) { vm_wait(ph.pps + pend1); if (lane == 0) ctl[W_FULL + mine2 % NSLOT] = (unsigned)(mine2 + 1); }
+        }
+        ETR_ADD(lw * 4 + 2);          // loader: waiting for DMAs to land
       }
+      mine3 = mine2; mine2 = mine1; mine1 = s;
       pend2 = pend1; pend1 = ph.pps;
     }
   }
-  (void)pend2;
-  if (s >= 2) { vm_wait(pend1); if (lane == 0) ctl[W_FULL + (s - 2) % NSLOT] = (unsigned)(s - 1); }
-  if (s >= 1) { vm_wait(0); if (lane == 0) ctl[W_FULL + (s - 1) % NSLOT] = (unsigned)s; }
+  (void)mine3; (void)pend2;
+  if (LDEPTH >= 2 && mine2 >= 0) { vm_wait(pend1); if (lane == 0) ctl[W_FULL + mine2 % NSLOT] = (unsigned)(mine2 + 1); }
+  if (LDEPTH >= 1 && mine1 >= 0) { vm_wait(0); if (lane == 0) ctl[W_FULL + mine1 % NSLOT] = (unsigned)(mine1 + 1); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- gather
@@ -256,7 +293,7 @@ __device__ __forceinline__ void consumer(const usdm_gemv_chain_args& c, char* sm
     if (cw == 0) gather(c, p, src, xs, ctl, gen * 4u + (unsigned)src + 1u, tmo, failed, lane);
     else if (!lds_wait(ctl, c.sync + 1, tmo, [&]() { return lds_ld(ctl + W_READY + p) != 0u; })) return;
     const unsigned epoch = gen * 4u + (unsigned)p + 1u;
-    for (int job = cw; job < ph.njobs; job += 3) {
+    for (int job = cw; job < ph.njobs; job += NC) {
       const int u0 = cu * ph.upc + 2 * job;     // outputs u0, u0 + 1
       float r[2];
       if (!ph.kindB) {
@@ -266,7 +303,12 @@ __device__ __forceinline__ void consumer(const usdm_gemv_chain_args& c, char* sm
           if (h == 1 && !ph.glu) break;
           const int s = sbase + job * ph.spj + h;
           const int i = s % NSLOT;
-          if (!lds_wait(ctl, c.sync + 1, tmo, [&]() { return lds_ld(ctl + W_FULL + i) == (unsigned)(s + 1); })) return;
+          {
+            ETR_T0();
+            if (!lds_wait(ctl, c.sync + 1, tmo, [&]() { return lds_ld(ctl + W_FULL + i) == (unsigned)(s + 1); })) return;
+            ETR_ADD(32 + cw * 4 + 0);   // consumer: waiting for a full slot
+          }
+          ETR_T0();
           const char* slot = smem + i * SLOTB;
           float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -280,6 +322,7 @@ __device__ __forceinline__ void consumer(const usdm_gemv_chain_args& c, char* sm
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (lane == 0) ctl[W_FREE + i] = (unsigned)(s + 1);      // the slot's bytes are in registers: hand it back
           a0 = wave_sum(a0); a1 = wave_sum(a1);
+          ETR_ADD(32 + cw * 4 + 1);     // consumer: reads + dots + reduction of one slot
           if (ph.glu) {
             if (a.round_bf16) {
               const float gt = round_bf(a0), up = round_bf(a1);
@@ -344,7 +387,7 @@ __device__ __forceinline__ void consumer(const usdm_gemv_chain_args& c, char* sm
   }
 }
 
-__global__ __launch_bounds__(256) void gemv_engine_kernel(const usdm_gemv_chain_args c) {
+__global__ __launch_bounds__((NL + NC) * 64) void gemv_engine_kernel(const usdm_gemv_chain_args c) {
   __shared__ __attribute__((aligned(16))) char smem[ELDS];   // (static: the >64 KiB dynamic-LDS attribute is refused for this kernel)
   lds_u32* ctl = (lds_u32*)(__attribute__((address_space(3))) char*)(smem + CTL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -355,14 +398,21 @@ __global__ __launch_bounds__(256) void gemv_engine_kernel(const usdm_gemv_chain_
   if (tid < 32) ctl[tid] = 0u;   // FULL / FREE / READY / ABORT words
   __syncthreads();
   const unsigned long long tmo = (unsigned long long)c.timeout_ms * 100000ull;
-  if (wave == 0) loader(c, smem, ctl, tmo, lane);
-  else consumer(c, smem, ctl, gen, tmo, failed, wave - 1, lane);
+  if (wave < NL) loader(c, smem, ctl, tmo, wave, lane);
+  else consumer(c, smem, ctl, gen, tmo, failed, wave - NL, lane);
   // the gathering wave of workgroup 0 opens the next generation: it can only get here after every workgroup has published
   // (hence started and read `gen`) whenever the chain has a hand-off; single-phase launches do not use the generation
-  if (blockIdx.x == 0 && wave == 1 && lane == 0 && c.nph > 1)
+  if (blockIdx.x == 0 && wave == NL && lane == 0 && c.nph > 1)
     __hip_atomic_store(c.sync + 0, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
+
+#ifdef USDM_ENG_TRACE
+extern "C" int usdm_dbg_eng_trace(unsigned long long* host, int reset) {
+  if (reset) { unsigned long long z[64] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_eng_trace), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_eng_trace), sizeof(unsigned long long) * 64);
+}
+#endif
 
 extern "C" int usdm_gemv_engine(const usdm_gemv_chain_args* pc, usdm_stream_t stream) {
   USDM_CHECK_ARG(pc && pc->nph >= 1 && pc->nph <= USDM_CHAIN_MAX_PHASES && pc->sync && pc->gran && pc->timeout_ms > 0,
@@ -394,7 +444,7 @@ extern "C" int usdm_gemv_engine(const usdm_gemv_chain_args* pc, usdm_stream_t st
   }
   usdm_gemv_chain_args c = *pc;
   for (int p = 0; p < c.nph; ++p) c.norm_nth[p] = usdm_gemv_threads(&c.ph[p]);
-  hipLaunchKernelGGL(gemv_engine_kernel, dim3(NCU), dim3(256), 0, (hipStream_t)stream, c);
+  hipLaunchKernelGGL(gemv_engine_kernel, dim3(NCU), dim3((NL + NC) * 64), 0, (hipStream_t)stream, c);
   USDM_LAUNCH_CHECK();
   return 0;
 }
