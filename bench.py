@@ -70,7 +70,7 @@ class Pipeline:
                     probe.close()
                 except Exception as e:  # noqa: BLE001
                     why = repr(e)
-                flag = torch.tensor([0 if why is None else 1], device=dev)
+                flag = torch.tensor([0 if why is None else 1], device="cpu" if dist.get_backend(group) == "gloo" else dev)
                 dist.all_reduce(flag, group=group)          # every rank must take the same decision
                 if int(flag.item()) == 0:
                     comm = P2PComm.from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
@@ -364,6 +364,14 @@ def main():
         return launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # USDM_BENCH_SHARE_GPU=1 (validation of the multi-rank path on a box with fewer GPUs than ranks): ranks share devices, the
+    # process group is gloo (RCCL refuses two ranks on one device; the prefill collectives are then staged through the host) and
+    # the decode exchange is the peer-to-peer one over hipIpc.  Numbers from such a run are not scaling results.
+    share = os.environ.get("USDM_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if world > ndev and not share:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s) (USDM_BENCH_SHARE_GPU=1 lets ranks share a device for validation)")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
@@ -373,7 +381,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share and world > ndev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
     def barrier():
@@ -396,7 +407,8 @@ def main():
     dt = time.perf_counter() - t0
     if dist_on:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        host = dist.get_backend() == "gloo"
+        t = torch.tensor([dt], device="cpu" if host else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stages = pipe.stage_ms()  # last step
@@ -414,7 +426,9 @@ def main():
                                "Token-Voicebox 63 NFE (Heun, CFG, 3 s prompt) -> BigVGAN",
                    "wave_samples": 160000, "prompt_tokens": list(pipe.prompt_lens), "generated_tokens": pipe.n_generated,
                    "voicebox_n_timesteps": args.nt, "mel_frames": pipe.frames, "output_samples": int(audio.shape[0]),
-                   "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm},
+                   "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm,
+                   **({"shared_gpu_validation": f"{world} ranks on {torch.cuda.device_count()} GPU(s): code-path validation, not a scaling result"}
+                      if os.environ.get("USDM_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count() else {})},
         "llm_tokens_per_s": round(pipe.n_generated / (llm_ms * 1e-3), 2),
         "llm_decode_tokens_per_s_tts_round": round(args.units / (stages["llm_tts"] * 1e-3), 2),
         "stage_ms": {k: round(v, 2) for k, v in stages.items()},
