@@ -63,10 +63,11 @@ class Pipeline:
                 import torch.distributed as dist
                 from usdm_amd.llm import MISTRAL_7B_USDM as C7
                 from usdm_amd.p2p import P2PComm, self_test
-                why = None
+                why, fused = None, True
                 try:
-                    probe = P2PComm.from_process_group(group, 3, 1024, timeout_ms=3000)
-                    why = self_test(probe, group, dev)
+                    fused = os.environ.get("USDM_P2P_FUSED", "1") == "1"
+                    probe = P2PComm.from_process_group(group, 3, 4096, timeout_ms=3000)
+                    why = self_test(probe, group, dev, fused=fused)
                     probe.close()
                 except Exception as e:  # noqa: BLE001
                     why = repr(e)
@@ -74,7 +75,8 @@ class Pipeline:
                 dist.all_reduce(flag, group=group)          # every rank must take the same decision
                 if int(flag.item()) == 0:
                     comm = P2PComm.from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
-                    self.tp_comm = "p2p (one-shot xGMI exchange fused into the row-parallel GEMV epilogues; self-test passed)"
+                    self.tp_comm = ("p2p (one-shot xGMI exchange fused into the row-parallel GEMV epilogues; self-test passed)" if fused else
+                                    "p2p, split form (put in the GEMV epilogue + reduce launch; self-test passed)")
                 else:
                     self.tp_comm = f"rccl (p2p self-test failed on {int(flag.item())} rank(s): {why})"
         self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group,

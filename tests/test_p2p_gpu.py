@@ -126,8 +126,10 @@ def _proc(rank, world, port, q):
         from usdm_amd.llm import USDMForCausalLM
         from usdm_amd.p2p import P2PComm
         from usdm_amd.p2p import self_test
-        probe = P2PComm.from_process_group(dist.group.WORLD, 3, 1024)
-        verdict = self_test(probe, dist.group.WORLD, dev)      # the start-up check bench.py runs before trusting the transport
+        probe = P2PComm.from_process_group(dist.group.WORLD, 3, 4096)
+        verdict = self_test(probe, dist.group.WORLD, dev, N=1024)       # the start-up check bench.py runs (smaller grid: the two ranks share this GPU)
+        assert verdict is None, verdict
+        verdict = self_test(probe, dist.group.WORLD, dev, fused=False)   # split form at the real 4096-output shape
         assert verdict is None, verdict
         probe.close()
         comm = P2PComm.from_process_group(dist.group.WORLD, 2 * CFG["num_hidden_layers"] + 1, CFG["hidden_size"])

@@ -171,11 +171,13 @@ class InProcessGroup:
             self._pend = []
 
 
-def self_test(comm, group, device, rounds=4, N=1024, K=512):
+def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
     """Start-up check of a freshly wired communicator across the REAL ranks of `group`: `rounds` fused all-reduces (the GEMV
     epilogue form, both parities) checked against the group's own all_reduce of the same f32 partials, and `rounds` cross-rank
-    token picks checked against the known winner.  Returns None if everything matches, else a description of what failed
-    (callers fall back to the RCCL path)."""
+    token picks checked against the known winner.  The default shape is the o_proj shard of the 7B at TP = 8 (4096 outputs: the
+    256-workgroup, 16-wave launch the decode step uses), so that a node on which those grids cannot make progress fails HERE.
+    fused=False checks the split form (put in the epilogue + usdm_allreduce_p2p_reduce).  Returns None if everything matches,
+    else a description of what failed (callers fall back to the RCCL path)."""
     import torch
     import torch.distributed as dist
     from . import ops
@@ -199,7 +201,10 @@ def self_test(comm, group, device, rounds=4, N=1024, K=512):
                 tot = part.clone(); dist.all_reduce(tot, group=group)
             want = (h0.float() + tot.to(torch.bfloat16).float()).to(torch.bfloat16)
             h = h0.clone()
-            ops.gemv(W, x, N=N, K=K, residual=h, y16=h, p2p=comm, p2p_site=it % (comm.n_sites - 1), p2p_mode=1)   # (the last site is the token pick's)
+            site = it % (comm.n_sites - 1)            # (the last site is the token pick's)
+            ops.gemv(W, x, N=N, K=K, residual=h, y16=h, p2p=comm, p2p_site=site, p2p_mode=1 if fused else 2)
+            if not fused:
+                ops.p2p_reduce(comm, site, N, h)
             torch.cuda.synchronize()
             err, _ = comm.status()
             if err:
