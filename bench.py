@@ -110,6 +110,7 @@ class Pipeline:
     def step(self):
         a, dev = self.args, self.dev
         self.ev = {}
+        self.llm._kv_ids = None       # utterances are independent: nothing cached by the previous step may be reused
         self._mark("t0")
         units = self.ue.predict(self.wave, 34)                                        # [499]
         self._mark("tok")

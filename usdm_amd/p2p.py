@@ -185,6 +185,7 @@ def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
         if comm.n_sites < 2:
             return "self-test needs at least two sites (rows + token pick)"
         rank, world = comm.rank, comm.world
+        _, ep0 = comm.status()
         staged = dist.get_backend(group) == "gloo"
         g = torch.Generator().manual_seed(1000 + rank)
         gs = torch.Generator().manual_seed(999)          # shared by all ranks
@@ -225,8 +226,8 @@ def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
             if int(nxt.item()) != 100 * (it % world) + 2:
                 return f"round {it}: cross-rank token pick returned {int(nxt.item())}"
         err, ep = comm.status()
-        if err or ep != 1 + rounds:
-            return f"status after self-test: error word {err:#x}, epoch {ep} (expected {1 + rounds})"
+        if err or ep != ep0 + rounds:
+            return f"status after self-test: error word {err:#x}, epoch {ep} (expected {ep0 + rounds})"
         return None
     except Exception as e:  # noqa: BLE001 - any failure means: do not use this transport
         return f"self-test raised {e!r}"
