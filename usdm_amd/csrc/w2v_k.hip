@@ -40,39 +40,61 @@ __global__ __launch_bounds__(1024) void wave_norm_kernel(const float* __restrict
 }
 
 // First feature-extractor layer fused: Conv1d(1 -> C, k, stride) + LayerNorm(C) + GELU, channels-last out.
-// One wave per output frame; lane owns C/64 channels (C = 512 -> 8).
-template <int CPL, int KW>
-__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, int T, int stride, const float* __restrict__ w,
+// A workgroup owns FR consecutive output frames: their input window ((FR-1)*stride + k samples, contiguous) is staged in LDS
+// once with coalesced loads, the lane's CPL channels' taps / bias / LayerNorm parameters are fetched once into registers, and
+// every wave then walks its FR/4 frames reading the window from LDS (broadcast reads) - instead of every frame's wave
+// re-fetching the 20 KB of taps and its samples from L2.  One wave per output frame for the LayerNorm reduction;
+// lane owns C/64 channels (C = 512 -> 8).  Per frame the arithmetic is unchanged.
+template <int CPL, int KW, int FR>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, int n, int T, int stride, const float* __restrict__ w,
                                                     const float* __restrict__ b, const float* __restrict__ g,
                                                     const float* __restrict__ be, float eps, float* __restrict__ out) {
   constexpr int C = CPL * 64;
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  float xv[KW];
-#pragma unroll
-  for (int j = 0; j < KW; ++j) xv[j] = x[(int64_t)t * stride + j];
-  float v[CPL];
-  float s = 0.f;
+  constexpr int MAXW = (FR - 1) * 8 + KW;          // window for strides up to 8
+  __shared__ float win[MAXW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * FR;
+  const int64_t x0 = (int64_t)t0 * stride;
+  const int nwin = (FR - 1) * stride + KW;
+  for (int i = tid; i < nwin; i += 256) win[i] = (x0 + i < n) ? x[x0 + i] : 0.f;
+  float wv[CPL][KW], bv[CPL], gv[CPL], bev[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lane * CPL + c;
-    float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < KW; ++j) a = fmaf(w[ch * KW + j], xv[j], a);
-    a += b[ch];
-    v[c] = a;
-    s += a;
+    for (int j = 0; j < KW; ++j) wv[c][j] = w[ch * KW + j];
+    bv[c] = b[ch]; gv[c] = g[ch]; bev[c] = be[ch];
   }
-  const float mean = wave_sum(s) * (1.0f / C);
-  float q = 0.f;
+  __syncthreads();
+  for (int f = wave; f < FR; f += 4) {
+    const int t = t0 + f;
+    if (t >= T) break;
+    float xv[KW];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) { const float d = v[c] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+    for (int j = 0; j < KW; ++j) xv[j] = win[f * stride + j];
+    float v[CPL];
+    float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int ch = lane * CPL + c;
-    out[(int64_t)t * C + ch] = gelu_erf((v[c] - mean) * rstd * g[ch] + be[ch]);
+    for (int c = 0; c < CPL; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) a = fmaf(wv[c][j], xv[j], a);
+      a += bv[c];
+      v[c] = a;
+      s += a;
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const float d = v[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+    float o[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) o[c] = gelu_erf((v[c] - mean) * rstd * gv[c] + bev[c]);
+    float4* dst = (float4*)(out + (int64_t)t * C + lane * CPL);
+    static_assert(CPL % 4 == 0, "channels per lane");
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4) dst[c / 4] = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
   }
 }
 
@@ -147,7 +169,9 @@ extern "C" int usdm_w2v_conv0(const float* x, int32_t n, int32_t T, int32_t C, i
   USDM_CHECK_ARG(x && w && b && ln_g && ln_b && out && T > 0, "usdm_w2v_conv0: null args");
   USDM_CHECK_ARG((int64_t)(T - 1) * stride + k <= n, "usdm_w2v_conv0: T frames do not fit in n samples");
   USDM_CHECK_ARG(C == 512 && k == 10, "usdm_w2v_conv0: built for the XLS-R first layer (1->512, k=10); got C=%d k=%d", C, k);
-  hipLaunchKernelGGL((conv0_kernel<8, 10>), dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, T, stride, w, b, ln_g, ln_b, eps, out);
+  USDM_CHECK_ARG(stride >= 1 && stride <= 8, "usdm_w2v_conv0: stride %d outside the staged window's range (1..8)", stride);
+  constexpr int FR = 64;   // frames per workgroup: 325 staged samples at stride 5
+  hipLaunchKernelGGL((conv0_kernel<8, 10, FR>), dim3(cdiv(T, FR)), dim3(256), 0, (hipStream_t)stream, x, n, T, stride, w, b, ln_g, ln_b, eps, out);
   USDM_LAUNCH_CHECK();
   return 0;
 }
