@@ -75,6 +75,7 @@ def test_generate_sampling(dev):
     cfg = dict(vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
                num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=32768)
     m = USDMForCausalLM.random_init(cfg, dev, seed=5, ctx_max=256)
+    m.reuse_prefix = False        # (every call below prefills the same 40 tokens: one plan per {greedy, sampling} is then the invariant)
     ids = torch.randint(0, 1000, (1, 40), generator=torch.Generator().manual_seed(1)).to(dev)
     bad = [[i] for i in range(0, 500)]
     kw = dict(input_ids=ids, max_new_tokens=24, do_sample=True, bad_words_ids=bad, temperature=1.5, top_p=0.95)
