@@ -201,7 +201,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int NWV = NWM * NWN;
   constexpr int NIA = (QA + NWV - 1) / NWV, NIB = (QB + NWV - 1) / NWV;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const bool simple = (a.taps == 1);                     // Linear layers: no per-tap row remap
+  // The LDS-DMA variants serve single-tap operands only (Linear layers: no per-tap row remap; the launcher routes multi-tap
+  // operands to the register-staged loaders), so the tap arithmetic - an integer division per instruction - is not even
+  // compiled into their K loop.
+  constexpr bool simple = DMA;
   unsigned dofA[NIA], dofB[NIB];                         // byte offset of (row, swizzled piece) at chunk 0; >= 2^31 if the row is out of range
   int drA[NIA];                                          // tile row of the A instruction (multi-tap path)
   if constexpr (DMA) {
@@ -735,6 +738,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
+  if (a.taps != 1 && sel >= 4) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
     if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);
