@@ -25,7 +25,7 @@ for _ in range(5):
     if QKV:
         ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, qkv=dict(S=S, Spad=Spad, H=16, D=64, q=q, k=k, v=vt))
     else:
-        ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, out16=out)
+        ops.gemm(A, W, M=M, N=N, Kc=K, bias=bias, out16=out, act=1 if "--gelu" in sys.argv else 0)
 torch.cuda.synchronize()
 lib = _lib.lib
 buf = np.zeros(8192 * 8, dtype=np.uint64)
@@ -51,7 +51,7 @@ for i, nm in enumerate(names):
 d = ns(t[:, 6] - t[:, 4]) / 1e3
 print(f"  {'  stores issued':18s} median {np.median(d):6.2f} us  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}")
 if QKV:   # the last third of the tiles along N holds V (transposed store)
-    bm = 128 if nwg in (18 * 24, 18 * 48) else 64
+    bm = 256 if nwg == 9 * 24 else (128 if nwg in (18 * 24, 18 * 48) else 64)
     tiles_n = nwg // ((M + bm - 1) // bm)
     q8, r8 = nwg // 8, nwg % 8
     bid = np.arange(nwg); xcd = bid & 7; idx = bid >> 3

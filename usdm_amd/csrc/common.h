@@ -88,4 +88,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (z < 0.f ? q : 2.0f - q);
 }
 
+// the same GELU on two values at once: the f32 arithmetic is written on 2-vectors (v_pk_fma_f32 / v_pk_mul_f32, two results per
+// VALU instruction) and the reciprocal is the hardware approximation (1 ulp; __frcp_rn expands to the 10-instruction IEEE
+// division).  For the GEMM epilogues that run at one workgroup per CU, where nothing hides the activation's VALU time.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t z = x * 0.70710678118654752440f;
+  const f32x2_t az = {fabsf(z.x), fabsf(z.y)};
+  const f32x2_t d = fma2(az, f32x2_t{0.3275911f, 0.3275911f}, f32x2_t{1.0f, 1.0f});
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2_t p = fma2(t, f32x2_t{1.061405429f, 1.061405429f}, f32x2_t{-1.453152027f, -1.453152027f});
+  p = fma2(t, p, f32x2_t{1.421413741f, 1.421413741f});
+  p = fma2(t, p, f32x2_t{-0.284496736f, -0.284496736f});
+  p = fma2(t, p, f32x2_t{0.254829592f, 0.254829592f});
+  const f32x2_t w = az * az * -1.4426950408889634f;                 // exp(-az^2) = 2^(-az^2 log2 e)
+  const f32x2_t e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2_t q = p * t * e;
+  const f32x2_t r = {z.x < 0.f ? q.x : 2.0f - q.x, z.y < 0.f ? q.y : 2.0f - q.y};
+  return x * 0.5f * r;
+}
+typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2v(f32x2_t v) {          // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v_t));
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

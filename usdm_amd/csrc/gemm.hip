@@ -25,6 +25,7 @@ namespace {
 struct GemmDev {
   usdm_gemm_args a;
   int tiles_m, tiles_n;
+  int dbg;   // USDM_GEMM_DBG (ablation switches of the ping-pong loop: 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads)
 };
 
 // compile-time loop: every accumulator index below is a constant, so nothing can fall into scratch
@@ -56,8 +57,30 @@ __device__ unsigned long long g_gemm_trace[8192 * 8];
 #define TR(i) do { } while (0)
 #endif
 
-template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2>
-// NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct with NST LDS stages of NCH 64-byte chunks each
+// bias of this thread's epilogue columns -> registers (SwiGLU: gate / up), per-column bias of the transposed epilogues -> LDS.
+// A macro, not a lambda: captured by reference the small arrays fall into scratch.  Expanded before the K loop, or - ping-pong
+// variants - behind the first LDS-DMA.
+#define USDM_GEMM_FETCH_BIAS()                                                                                              \
+  do {                                                                                                                      \
+    if (bias) {                                                                                                             \
+      if (swiglu) {                                                                                                         \
+        const int c4 = (tid % (BN / 8)) * 4;                                                                                \
+        const int ngate = n0 + (c4 >> 4) * 32 + (c4 & 15);                                                                  \
+        if (ngate < a.N) {                                                                                                  \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) { bv[e] = bias[gcol + ngate + e]; bu[e] = bias[gcol + ngate + 16 + e]; } \
+        }                                                                                                                   \
+      } else {                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                       \
+          if (n0 + ec + e < a.N) bv[e] = bias[gcol + n0 + ec + e];                                                          \
+      }                                                                                                                     \
+    }                                                                                                                       \
+    if (tr_mode)                                                                                                            \
+      for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;                       \
+  } while (0)
+
+template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2, bool PP = false>
+// NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct with NST LDS stages of NCH 64-byte chunks each;
+// PP: the 8-wave ping-pong K loop (two wave groups one barrier apart, see below)
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const usdm_gemm_args& a = g.a;
   constexpr int NTH = NWM * NWN * 64;
@@ -73,7 +96,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int CSTT = BM + 16;              // f32 column stride of the TRANSPOSED epilogue tile (outputs whose fast axis is m)
   constexpr int EPI = (BM * CST > BN * CSTT ? BM * CST : BN * CSTT) * 4;
   constexpr int SMEM = (NST * STAGE > EPI) ? NST * STAGE : EPI;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  // ONE LDS object (staging ring / epilogue tile + the per-column bias of the transposed epilogues): a second __shared__ array
+  // beside an LDS-DMA ring can make hipcc drain the ring (vmcnt(0)) before every fragment read
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + BN * 4];
 
   const int tid = threadIdx.x;
   TR(0);
@@ -167,27 +192,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int C4 = BN / 4, RPI = NTH / C4, NIT = BM / RPI;
   const int ec = (tid % C4) * 4, er = tid / C4;
   float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};   // SwiGLU: gate / up
-  if (bias) {
-    if (swiglu) {
-      const int c4 = (tid % (BN / 8)) * 4;
-      const int ngate = n0 + (c4 >> 4) * 32 + (c4 & 15);
-      if (ngate < a.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bv[e] = bias[gcol + ngate + e]; bu[e] = bias[gcol + ngate + 16 + e]; }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n0 + ec + e < a.N) bv[e] = bias[gcol + n0 + ec + e];
-    }
-  }
-
   // outputs whose fast axis is m (transpose_out, V^T tiles of the head-split epilogue) go through a transposed LDS tile;
-  // their per-column bias is staged in LDS here (visible after the K loop's barriers)
+  // their per-column bias is staged in LDS (visible after the K loop's barriers)
   const bool tr_mode = a.transpose_out != 0 || (a.epi == USDM_EPI_QKV_HEADS && n0 >= 2 * a.qkv_H * a.qkv_D);
-  __shared__ float sb[BN];
-  if (tr_mode)
-    for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;
+  float* sb = (float*)(smem + SMEM);
+  if constexpr (!PP) USDM_GEMM_FETCH_BIAS();   // the ping-pong variants fetch it behind their first LDS-DMA instead
 
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr bool simple = DMA;
   unsigned dofA[NIA], dofB[NIB];                         // byte offset of (row, swizzled piece) at chunk 0; >= 2^31 if the row is out of range
   int drA[NIA];                                          // tile row of the A instruction (multi-tap path)
-  if constexpr (DMA) {
+  if constexpr (DMA && !PP) {
     const int lrow = lane >> 2, lp = lane & 3;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
@@ -264,6 +273,63 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     }
   };
 
+  // ---- ping-pong variants (PP): LDS image of an operand = [row / 8][8 rows][8 pieces of 16 B]: ONE LDS-DMA instruction moves 8 rows x
+  // 128 B, i.e. whole cache lines (half-line pieces cost the texture path twice the lines per byte).  The piece index is XORed with
+  // (row >> 1) & 7 on the source side, which makes the ds_read_b128 of a 16x16x32 fragment of either K half conflict-free.
+  // A wave issues PFA + PFB whole instructions per K-step and, when BM / 8 is not a multiple of the wave count, one half
+  // instruction (32 lanes = 4 rows) of the leftover blocks: NPW = the per-wave, per-step count the vmcnt waits are written in.
+  constexpr int PBA = BM / 8, PBB = BN / 8;
+  constexpr int PFA = PBA / NWV, PLA = PBA % NWV, PFB = PBB / NWV;
+  constexpr int PNF = PFA + PFB, NPW = PNF + (PLA ? 1 : 0);
+  static_assert(!PP || (PBB % NWV == 0 && (PLA == 0 || PLA == 4) && PNF % 2 == 0), "ping-pong DMA split");
+  unsigned pofs[PNF + 1];                                // source byte offsets at chunk 0 (>= 2^31: row out of range): A..., W..., leftover A
+  unsigned phi = 0;                                      // bit i: instruction i of this lane fetches a piece of the SECOND half of the step
+  if constexpr (PP) {
+    const int lrow = lane >> 3, lp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < PFA + (PLA ? 1 : 0); ++i) {
+      const int blk = i < PFA ? wv + NWV * i : PFA * NWV + (wv >> 1);
+      const int r = blk * 8 + lrow;
+      const int row = (m0 + r) * a.a_row_mul + a.a_row_off;
+      const bool v = (unsigned)row < (unsigned)a.rowsA;
+      const int pc2 = lp ^ ((r >> 1) & 7);
+      pofs[i < PFA ? i : PNF] = (v ? (unsigned)row * lda_b : 0xC0000000u) + (unsigned)(pc2 << 4);
+      phi |= (unsigned)(pc2 >> 2) << (i < PFA ? i : PNF);
+    }
+#pragma unroll
+    for (int i = 0; i < PFB; ++i) {
+      const int r = (wv + NWV * i) * 8 + lrow;
+      const bool v = (n0 + r) < a.N;
+      const int pc2 = lp ^ ((r >> 1) & 7);
+      pofs[PFA + i] = (v ? (unsigned)(n0 + r) * ldw_b : 0xC0000000u) + (unsigned)(pc2 << 4);
+      phi |= (unsigned)(pc2 >> 2) << (PFA + i);
+    }
+  }
+  // part 0 / 1: the instructions issued in the first / second phase of a step; 2: all.  chk: the step's second half lies past K
+  auto pp_issue = [&](int slot, int step, int part, bool chk) {
+    if constexpr (PP) {
+      char* sAs = smem + slot * STAGE;
+      char* sBs = sAs + BM * 128;
+      const unsigned kcol = (unsigned)((q_lo + 2 * step) * 64);
+#pragma unroll
+      for (int i = 0; i < PNF; ++i) {
+        if (part != 2 && (i < PNF / 2) != (part == 0)) continue;
+        unsigned off = pofs[i] + kcol;
+        if (chk && ((phi >> i) & 1)) off = OOB;
+        if (i < PFA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (wv + NWV * i) * 1024), 16, off, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBs + (wv + NWV * (i - PFA)) * 1024), 16, off, 0, 0, 0);
+      }
+      if (PLA && part != 0) {
+        unsigned off = pofs[PNF] + kcol;
+        if (chk && ((phi >> PNF) & 1)) off = OOB;
+        if ((lane >> 5) == (wv & 1))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (PFA * NWV + (wv >> 1)) * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
   auto compute = [&](int stage, auto&& between) {
     const char* sA = smem + stage * STAGE;
     const char* sB = sA + BM * 64 * NCH;
@@ -303,7 +369,92 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // Small tiles (cheap in registers, short MFMA phase) keep TWO K-steps of loads in flight in two register
   // sets; the 128x128 tile keeps one (a second set would halve its occupancy: measured slower).
   constexpr bool PF2 = (BM * BN <= 128 * 64) || (NTH > 256);
-  if constexpr (DMA) {
+  if constexpr (PP) {
+    // ---- 8-wave ping-pong loop for big tiles at one workgroup per CU (cdna_hip_programming.md 5, "8-phase template", re-cut).
+    // Waves w and w + 4 share a SIMD; group 1 (waves 4-7) runs ONE barrier behind group 0, so that on every SIMD one wave
+    // multiplies (MFMA section, raised priority) while its partner reads fragments and issues LDS-DMA.  A K-step is 64 deep and
+    // owns one of the 3 LDS slots; a phase is one 32-deep half of it: TM + TN ds_read_b128, half of the DMA instructions of
+    // step s + 2, TM x TN MFMAs, two raw barriers.
+    //   RAW  the counted vmcnt that retires step s + 1 sits before the first barrier of phase (s, 1) in BOTH groups; group 0
+    //        reads step s + 1 after its second barrier of that phase (= group 1's first), group 1 one barrier later still;
+    //   WAR  slot (s + 2) % 3 held step s - 1; every wave retires its fragment reads (lgkmcnt(0)) BEFORE the first barrier of
+    //        the phase that issued them, so group 1's last reads of step s - 1 are complete one barrier before group 0's issue.
+    static_assert(DMA && NCH == 2 && NST == 3 && NWM * NWN == 8 && sizeof(T) == 2, "ping-pong loop: 8 waves, bf16, 3 slots of 64-deep K-steps");
+    const int grp = wv >> 2;
+    const int nst = nks;                                   // K-steps (NCH = 2 chunks each)
+    const bool odd_tail = ((q_hi - q_lo) & 1) != 0;        // the last step has only its first half
+    TR(1);
+    if (nst > 0) pp_issue(0, 0, 2, nst == 1 && odd_tail);
+    if (nst > 1) pp_issue(1, 1, 2, nst == 2 && odd_tail);
+    if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TR(2);
+    USDM_GEMM_FETCH_BIAS();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    // fragment byte offsets of this lane inside a slot, for either K half (loop invariants)
+    unsigned foA[2][TM], foB[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * WTM + i * 16 + lr;
+      foA[0][i] = (r >> 3) * 1024 + (r & 7) * 128 + ((lc ^ ((r >> 1) & 7)) << 4);
+      foA[1][i] = foA[0][i] ^ 64;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int r = wn * WTN + j * 16 + lr;
+      foB[0][j] = BM * 128 + (r >> 3) * 1024 + (r & 7) * 128 + ((lc ^ ((r >> 1) & 7)) << 4);
+      foB[1][j] = foB[0][j] ^ 64;
+    }
+    u32x4 fa[TM], fb[TN];
+    // one phase: half h of the step in `slot`; issue = DMA part h of step sn into slotn; wait_n: < 0 none, else the vmcnt bound
+    auto phase = [&](const int slot, const int h, const int slotn, const int sn, const bool issue, const bool chk, const int wait_n) {
+      const char* sS = smem + slot * STAGE;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4*)(sS + foB[h][j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(sS + foA[h][i]);
+      if (issue && !(g.dbg & 1)) pp_issue(slotn, sn, h, chk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wait_n > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      else if (wait_n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (!(g.dbg & 2))
+        static_for<TM>([&](auto I) {
+          static_for<TN>([&](auto J) {
+            acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
+                                                                acc[I][J], 0, 0, 0);
+          });
+        });
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    int s = 0;
+    // steady state, unrolled over the ring (slot indices and halves are constants): every step of a round issues a whole step
+    for (; s + 4 < nst; s += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        phase(u, 0, (u + 2) % 3, s + u + 2, true, false, -1);
+        phase(u, 1, (u + 2) % 3, s + u + 2, true, false, 1);
+      }
+    }
+    // the last steps: runtime slot, no issue past the end, the final step's DMA fully drained
+    int sl = s % 3, sln = (s + 2) % 3;
+    for (; s < nst; ++s) {
+      const bool more = s + 2 < nst;
+      const bool chk = odd_tail && s + 2 == nst - 1;
+      phase(sl, 0, sln, s + 2, more, chk, -1);
+      phase(sl, 1, sln, s + 2, more, chk, more ? 1 : 0);
+      if (++sl == 3) sl = 0;
+      if (++sln == 3) sln = 0;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __syncthreads();
+  } else if constexpr (DMA) {
     // two LDS stages; step ks+1 streams into the idle stage by LDS-DMA while step ks is multiplied
     // NST LDS stages: the DMA of K-step ks+NST-1 is issued while step ks is multiplied; a counted vmcnt leaves the
     // youngest NST-2 steps in flight across the barrier (raw s_barrier: __syncthreads() would drain them).
@@ -375,7 +526,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const bool rbf = a.round_bf16 != 0;
   const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
 
+  constexpr bool TR_OK = NTH % (BM / 4) == 0 && BN % (NTH / (BM / 4)) == 0;   // tile geometries the transposed store loops cover
   if (tr_mode) {
+    if constexpr (!TR_OK) return;   // (the launcher routes transposed outputs to the other tiles: usdm_gemm, sel == 13)
     // ---- transposed mode: the accumulator fragment of a lane is 4 consecutive rows of one column, i.e. one float4 of the
     // transposed tile; the store loop then reads float4s along m without bank conflicts (a strided read of the row-major
     // tile was 8-way conflicted: 10 us per 128x128 V tile)
@@ -389,34 +542,51 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     __syncthreads();
     TR(4);
     if (is_qkv) {
-      // V^T[b][h][d][s]: lane = 2 consecutive tokens, a wave (or half-wave) = one feature -> dense 4-byte-per-lane stores
-      constexpr int R2 = BM / 2, CPI2 = NTH / R2, NITV = BN / CPI2;
-      const int r2 = (tid % R2) * 2, c0v = tid / R2;
-      const int m = m0 + r2;
-      if (m < a.M) {
+      // V^T[b][h][d][s]: lane = 4 consecutive tokens of one feature, a wave = 256 tokens of it -> dense 8-byte-per-lane stores
+      // (4 bytes per lane took 5.5 us per 256x128 tile against 2.8 us for the Q / K tiles).  Lanes whose 4 tokens straddle a
+      // sequence end, the matrix end or an odd position store token by token.
+      constexpr int R4V = BM / 4, CPI4 = NTH / R4V, NITV = BN / CPI4;
+      const int r4 = (tid % R4V) * 4, c0v = tid / R4V;
+      const int m = m0 + r4;
+      const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
+      if (mv > 0) {
         const int HD2 = 2 * a.qkv_H * a.qkv_D;
         const int b0 = m / a.qkv_S, s0 = m - b0 * a.qkv_S;
-        const bool pair = (m + 1 < a.M) && (s0 + 1 < a.qkv_S) && ((s0 & 1) == 0);
-        float2 cv = *(const float2*)(ct + c0v * CSTT + r2);
-#pragma unroll 4
+        const bool quad = mv == 4 && (s0 + 3 < a.qkv_S) && ((s0 & 1) == 0);
+        int64_t tok[4];                                   // element offset of each token's (batch, position) inside V^T
+        {
+          int bb = b0, ss = s0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            tok[e] = (int64_t)bb * a.qkv_H * a.qkv_D * a.qkv_Spad + ss;
+            if (++ss == a.qkv_S) { ss = 0; ++bb; }
+          }
+        }
+        float4 cv = *(const float4*)(ct + c0v * CSTT + r4);
+        int vh = (n0 + c0v - HD2) / a.qkv_D, vd = (n0 + c0v - HD2) - vh * a.qkv_D;   // head / feature of this thread's column, advanced
+#pragma unroll 2                                                                       // incrementally (no division per column)
         for (int it = 0; it < NITV; ++it) {
-          const int c = c0v + it * CPI2, n = n0 + c;
+          const int c = c0v + it * CPI4, n = n0 + c;
           if (n >= a.N) break;
-          float v0 = cv.x, v1 = cv.y;
-          if (it + 1 < NITV) cv = *(const float2*)(ct + (c + CPI2) * CSTT + r2);
+          float v[4] = {cv.x, cv.y, cv.z, cv.w};
+          if (it + 1 < NITV) cv = *(const float4*)(ct + (c + CPI4) * CSTT + r4);
           const float bc = sb[c];
-          v0 = a.alpha * v0 + bc; v1 = a.alpha * v1 + bc;
-          if (rbf) { v0 = round_bf(v0); v1 = round_bf(v1); }
-          const int hn = n - HD2, h = hn / a.qkv_D, d = hn - h * a.qkv_D;
-          bf16_t* vrow = (bf16_t*)a.qkv_v + (((int64_t)b0 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad;
-          if (pair) {
-            *(unsigned*)(vrow + s0) = pack_bf2(v0, v1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = a.alpha * v[e] + bc;
+            if (rbf) v[e] = round_bf(v[e]);
+          }
+          const int h = vh, d = vd;
+          vd += CPI4;
+          while (vd >= a.qkv_D) { vd -= a.qkv_D; ++vh; }
+          bf16_t* vfeat = (bf16_t*)a.qkv_v + ((int64_t)h * a.qkv_D + d) * a.qkv_Spad;
+          if (quad) {
+            uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(vfeat + tok[0]) = p;
           } else {
-            vrow[s0] = f2bf(v0);
-            if (m + 1 < a.M) {                               // second token starts the next sequence
-              const int b1 = (m + 1) / a.qkv_S, s1 = (m + 1) - b1 * a.qkv_S;
-              ((bf16_t*)a.qkv_v)[(((int64_t)b1 * a.qkv_H + h) * a.qkv_D + d) * a.qkv_Spad + s1] = f2bf(v1);
-            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < mv) vfeat[tok[e]] = f2bf(v[e]);
           }
         }
       }
@@ -526,6 +696,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       const int hn = n - part * HD, qh = hn / a.qkv_D, qd = hn - qh * a.qkv_D;
       bf16_t* base = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k);
       float4 cv = *(const float4*)(ct + er * CST + ec);
+      int b = (m0 + er) / a.qkv_S, sq = (m0 + er) - b * a.qkv_S;    // batch / position of the row, advanced incrementally
 #pragma unroll 2
       for (int it = 0; it < NIT; ++it) {
         const int r = er + it * RPI, m = m0 + r;
@@ -537,10 +708,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           v[e] = a.alpha * v[e] + bv[e];
           if (rbf) v[e] = round_bf(v[e]);
         }
-        const int b = m / a.qkv_S, sq = m - b * a.qkv_S;
         uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
         *(uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;   // D % 4 == 0, N % 4 == 0 (host-checked)
+        sq += RPI;
+        while (sq >= a.qkv_S) { sq -= a.qkv_S; ++b; }
       }
+    }
+  } else if (PP && nv == 4 && vec_ok && a.act == USDM_ACT_GELU && !rbf && !resid && a.C16 && !C32p) {
+    // the feed-forward GELU epilogue of the one-workgroup-per-CU tiles: nothing overlaps it there, so it is written for VALU
+    // throughput (two values per instruction, no per-element dispatch)
+    const int64_t rstep = (int64_t)RPI * a.c_row_mul;
+    int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
+    const f32x2_t b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]};
+    float4 cv = *(const float4*)(ct + er * CST + ec);
+#pragma unroll 2
+    for (int it = 0; it < NIT; ++it, row += rstep) {
+      const int r = er + it * RPI;
+      if (m0 + r >= a.M) break;
+      const f32x2_t v01 = {cv.x, cv.y}, v23 = {cv.z, cv.w};
+      if (it + 1 < NIT) cv = *(const float4*)(ct + (r + RPI) * CST + ec);
+      const f32x2_t g01 = gelu_erf2(v01 * a.alpha + b01), g23 = gelu_erf2(v23 * a.alpha + b23);
+      uint2 p; p.x = pack_bf2v(g01); p.y = pack_bf2v(g23);
+      *(uint2*)((bf16_t*)a.C16 + row * a.ldc + gcol + n) = p;
     }
   } else if (nv == 4 && vec_ok && a.act != USDM_ACT_NONE) {
     // activation epilogues: ROLLED loop so the transcendental code exists once (an unrolled epilogue grew the kernel to
@@ -582,7 +771,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   } else if (nv == 4 && vec_ok) {
     // no activation: batches of NB rows, the residual rows of a batch all in flight before their first use (a load inside
     // the store loop costs a full memory latency per iteration: measured 14 us of a 33 us 128x128 tile)
-    constexpr int NB = NIT < 8 ? NIT : 8;
+    constexpr int NB = NIT < 8 ? NIT : (NIT % 8 == 0 ? 8 : (NIT % 6 == 0 ? 6 : (NIT % 4 == 0 ? 4 : 1)));
     static_assert(NIT % NB == 0, "epilogue batches");
     const bool has_res = resid != nullptr;
     const int64_t rstep = (int64_t)RPI * a.c_row_mul;
@@ -659,14 +848,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
 #endif
 }
 
-template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2>
+template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2, bool PP = false>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
   GemmDev g;
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
+  static const int dbg = getenv("USDM_GEMM_DBG") ? atoi(getenv("USDM_GEMM_DBG")) : 0;
+  g.dbg = dbg;
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1));
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH>), grid, dim3(NWM * NWN * 64), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH, PP>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
 }
@@ -719,11 +910,20 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t z = (int64_t)a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1);
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
-  int sel;  // 0-2: register-staged 128x128 / 128x64 / 64x64; 4-6: the same tiles with 2-stage LDS-DMA; 7-11: deeper DMA pipelines
+  int sel;  // 0-2: register-staged 128x128 / 128x64 / 64x64; 4-6: the same tiles with 2-stage LDS-DMA; 7-11: deeper DMA pipelines; 12-13: ping-pong
   // Single-tap GEMMs (Linear layers): chosen from tools/vb_gemm_bench.py (the Voicebox layer's GEMMs over cold weights) and
   // tools/bench_gemm_tiles.py, see profiles/r01_gemm_ablation.txt.  USDM_GEMM_HEUR=0 restores the register-staged choice.
   static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 1;
-  if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
+  // Big single-tap bf16 GEMMs: the 8-wave ping-pong tiles (256x128, or 288x128 when that saves a round of workgroups) at one
+  // workgroup per CU, 1.2-2x the 128x128 tile on the Voicebox and LLM-prefill shapes (profiles/r02_gemm_ablation.txt section 4)
+  const int64_t t12 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 128) * z, t13 = (int64_t)cdiv(a.M, 288) * cdiv(a.N, 128) * z;
+  const bool pp_ok = heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 && t12 >= 96 && a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256 &&
+                     (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
+  if (pp_ok) {
+    const int64_t c12 = cdiv(t12, 256) * 256, c13 = cdiv(t13, 256) * 288;     // rounds x rows per tile
+    sel = (!a.transpose_out && a.epi == USDM_EPI_PLAIN && c13 < c12) ? 13 : 12;
+  }
+  else if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
   else if (heur == 1 && a.taps == 1) {
     if (a.split_k > 1 && t128 >= 224 && t128 <= 512) sel = 4;          // split-K partials filling one round of the big tile
     else if (t128 >= 640) sel = 4;                                     // many rounds of the big tile
@@ -739,6 +939,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else sel = 2;
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
   if (a.taps != 1 && sel >= 4) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
+  if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
     if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);
@@ -749,7 +950,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 9) return launch<bf16_t, 128, 128, 2, 2, true, 4, 1>(a, st);
     if (sel == 10) return launch<bf16_t, 128, 64, 2, 2, true, 3, 2>(a, st);
     if (sel == 11) return launch<bf16_t, 128, 128, 2, 2, true, 3, 2>(a, st);
-    // (256x128 / 128x256 tiles were measured in round 2 and are not instantiated: profiles/r02_gemm_ablation.txt)
+    if (sel == 12) return launch<bf16_t, 256, 128, 4, 2, true, 3, 2, true>(a, st);   // 8-wave ping-pong loop, one workgroup per CU
+    if (sel == 13) return launch<bf16_t, 288, 128, 2, 4, true, 3, 2, true>(a, st);   // row-major epilogues only
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
