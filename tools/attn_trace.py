@@ -38,3 +38,10 @@ if hasattr(_lib.lib, "usdm_dbg_attn_trace"):
     print(f"workgroups {len(t)}, cycles per workgroup median {np.median(tot):.0f} (s_memtime ticks), tiles {np.median(t[:, 7]):.0f}")
     for i, nm in enumerate(names):
         print(f"  {nm:32s} {np.median(t[:, i]):9.0f}  ({100 * np.median(t[:, i]) / np.median(tot):4.1f} %)   per tile {np.median(t[:, i] / np.maximum(t[:, 7], 1)):7.0f}")
+    # per (head) medians: workgroup index = (z * gy + y) * gx + x, head = gy - 1 - (y + gy * z) // gz (slow-heads-first order)
+    lin = np.arange(len(t)) // 9
+    head = nh - 1 - lin // Bx
+    tick_us = 0.01   # s_memtime: 100 MHz
+    for hh in range(nh):
+        sel = head == hh
+        print(f"  head {hh:2d}: workgroup total median {np.median(tot[sel]) * tick_us:6.2f} us   softmax+PV share {100 * np.median((t[sel, 2] + t[sel, 3]) / tot[sel]):4.1f} %")

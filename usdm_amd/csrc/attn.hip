@@ -47,7 +47,13 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
 
   const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // (head, batch) of this workgroup.  Bidirectional ALiBi attention: heads are walked from the LAST (flattest slope: every
+  // key tile counts) to the first (steepest: most far tiles are skipped below), batches innermost, so that when the grid is
+  // a bit more than one round of workgroups the short ones are the stragglers' partners, not the long ones.
+  const int qb = blockIdx.x;
+  const int lin = blockIdx.y + gridDim.y * blockIdx.z;
+  const int h = MODE == 0 ? (int)gridDim.y - 1 - lin / (int)gridDim.z : (int)blockIdx.y;
+  const int b = MODE == 0 ? lin % (int)gridDim.z : (int)blockIdx.z;
   const int hk = h / (a.Hq / a.Hkv);
   const int q0 = qb * QB + wave * 32;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
@@ -222,6 +228,12 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[u][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    // A key tile whose best score lies 40 binades under the running maximum of EVERY query of the wave adds < 2^-34 to a
+    // softmax denominator that is >= 1 (no change in f32) and < 2^-40 |v| per key to the output: its exponentials and its
+    // P.V MFMAs are skipped.  With ALiBi (networks.py:319-341: slope 2^-(h+1)/2 per key of distance, key 0 unbiased) that is
+    // most far tiles of the steep heads; fully masked tiles (bucket padding, scores -1e30) drop out the same way.
+    const bool skip_tile = __all(mloc < m_run - 40.0f);
+    if (!skip_tile) {
     const float m_new = fmaxf(m_run, mloc);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[t], 0, 0, 0);
         }
       }
+    }
     ATR_ADD(3, tph);
     if (it + 1 < myn) store_tile((it + 1) & 1);
     if (it + 2 < myn) load_tile(kt + 2 * KS);
