@@ -105,6 +105,7 @@ typedef struct usdm_norm_args {
   const int32_t* valid_len; int32_t rows_per_batch;
   void* out32; void* out16; int64_t ldo;
   void* sum32; void* sum16; int64_t lds;
+  const float* res2; int32_t n_res2; int64_t res2_stride;   /* n_res2 more f32 addends [rows][ldr], res2_stride elements apart (split-K partials): x + res + res2[0] + ... */
 } usdm_norm_args;
 
 int usdm_norm(const usdm_norm_args* args, usdm_stream_t stream);

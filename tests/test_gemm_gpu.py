@@ -226,18 +226,19 @@ def tile_env():
         os.environ["USDM_GEMM_TILE"] = old
 
 
-@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("tile", [12, 13, 14])
 def test_pingpong_tiles_bit_identical(dev, tile, tile_env):
-    """The 8-wave ping-pong tiles (256x128 / 288x128, USDM_GEMM_TILE=12 / 13) accumulate every output in the same K order as the
+    """The 8-wave ping-pong tiles (256x128 / 288x128 / 128x128, USDM_GEMM_TILE=12 / 13 / 14) accumulate every output in the same K order as the
     128x128 LDS-DMA tile (4): plain, residual, split-K and head-split epilogues must be BIT-identical, ragged M / N / K (a K that
-    ends in half a 64-deep step, a split whose last step is short) included; the packed GELU epilogue within one bf16 ulp."""
+    ends in half a 64-deep step - with the step counts 3k + 5 at which that half step falls on a steady-state round of the
+    ring -, a split whose last step is short) included; the packed GELU epilogue within one bf16 ulp."""
     from usdm_amd import ops
 
     def run(t, f):
         tile_env(t)
         return f()
 
-    for (M, N, K) in [(600, 520, 352), (2236, 1024, 1024), (257, 384, 64), (1118, 4096, 320)]:
+    for (M, N, K) in [(600, 520, 352), (2236, 1024, 1024), (257, 384, 64), (1118, 4096, 320), (600, 520, 480), (300, 256, 288)]:
         A, W = _rand((M, K), torch.bfloat16, 31, 0.3).to(dev), _rand((N, K), torch.bfloat16, 32, 0.3).to(dev)
         b, R = _rand((N,), torch.float32, 33).to(dev), _rand((M, N), torch.float32, 34).to(dev)
 
@@ -271,6 +272,22 @@ def test_pingpong_tiles_bit_identical(dev, tile, tile_env):
         assert ulp <= 1, f"gelu {M}x{N}x{K}: {ulp} bf16 ulps"
         ref = torch.nn.functional.gelu(A.double().cpu() @ W.double().cpu().T + b.double().cpu())
         _check(gt.float(), ref, torch.bfloat16, K, "packed gelu")
+
+    # batched operand with an output row offset and a K that ends in half a step (the Voicebox input projection, networks.py:196)
+    S1, Nn, K, Bx = 1118, 1024, 1440, 2     # 22.5 steps of 64: the half step is the last one issued by a steady-state round
+    A, W = _rand((Bx * S1, K), torch.bfloat16, 38, 0.3).to(dev), _rand((Nn, K), torch.bfloat16, 39, 0.3).to(dev)
+    b = _rand((Nn,), torch.float32, 40).to(dev)
+
+    def batched():
+        o32 = torch.zeros((Bx * (S1 + 1), Nn), device=dev); o16 = torch.zeros((Bx * (S1 + 1), Nn), device=dev, dtype=torch.bfloat16)
+        ops.gemm(A, W, M=S1, N=Nn, Kc=K, lda=K, rowsA=S1, batch=Bx, a_bstride=S1 * K, c_bstride=S1 + 1, c_row_off=1, bias=b,
+                 out32=o32, out16=o16, ldc=Nn)
+        return o32, o16
+
+    for x, y in zip(run(4, batched), run(tile, batched)):
+        assert torch.equal(x, y), f"batched: tile {tile} differs from tile 4 ({(x != y).float().mean().item():.4f} of the elements)"
+    ref = (A.double().cpu().reshape(Bx, S1, K) @ W.double().cpu().T + b.double().cpu())
+    _check(run(tile, batched)[0].reshape(Bx, S1 + 1, Nn)[:, 1:], ref, torch.bfloat16, K, "batched vs reference")
 
     # head-split epilogue: two sequences whose boundary falls inside a tile at an even and at an odd position
     for S in (1118, 333):

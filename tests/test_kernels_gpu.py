@@ -35,6 +35,13 @@ def test_layernorm_and_rms(dev, C):
     _close(o32, ref, 2e-6, "ln f32")
     _close(o16.float(), ref, 1e-2, "ln bf16")
     _close(s32, x + r, 1e-7, "sum")
+    # further f32 addends (split-K partials): x + res + res2[0] + res2[1], summed in that order
+    r2 = _r((2, rows, C), 5)
+    ops.norm(x.to(dev), g.to(dev), b.to(dev), rows=rows, C=C, res=r.to(dev), res2=r2.to(dev), n_res2=2, res2_stride=rows * C,
+             out32=o32, sum32=s32)
+    tot = ((x + r) + r2[0]) + r2[1]
+    assert torch.equal(s32.cpu(), tot), "res2 sum order"
+    _close(o32, torch.nn.functional.layer_norm(tot.double(), (C,), g.double(), b.double(), 1e-5), 2e-6, "ln res2")
     # gelu + valid_len mask
     vl = torch.tensor([20, 5], dtype=torch.int32, device=dev)
     ops.norm(x[:36].contiguous().to(dev), g.to(dev), b.to(dev), rows=36, C=C, act=1, valid_len=vl, rows_per_batch=18, out32=o32)

@@ -56,6 +56,7 @@ class NormArgs(C.Structure):
         ("valid_len", C.c_void_p), ("rows_per_batch", C.c_int32),
         ("out32", C.c_void_p), ("out16", C.c_void_p), ("ldo", C.c_int64),
         ("sum32", C.c_void_p), ("sum16", C.c_void_p), ("lds", C.c_int64),
+        ("res2", C.c_void_p), ("n_res2", C.c_int32), ("res2_stride", C.c_int64),
     ]
 
 

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     };
     int s = 0;
     // steady state, unrolled over the ring (slot indices and halves are constants): every step of a round issues a whole step
-    for (; s + 4 < nst; s += 3) {
+    // (a round issues steps up to s + 4: it must stop short of a last step that is only half a step, whose DMA needs `chk`)
+    for (; s + 4 < nst - (odd_tail ? 1 : 0); s += 3) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         phase(u, 0, (u + 2) % 3, s + u + 2, true, false, -1);
@@ -919,7 +920,13 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t t12 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 128) * z, t13 = (int64_t)cdiv(a.M, 288) * cdiv(a.N, 128) * z;
   const bool pp_ok = heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 && t12 >= 96 && a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256 &&
                      (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
-  if (pp_ok) {
+  // ... and its 128x128 form where the big tiles would leave half the CUs idle (96-256 tiles of 128x128, one per CU)
+  const int64_t t14 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
+  static const int pp14 = getenv("USDM_GEMM_PP_SMALL") ? atoi(getenv("USDM_GEMM_PP_SMALL")) : 1;
+  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 && t12 < 128 && t14 >= 96 && t14 <= 256 &&
+                        a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256;
+  if (pp_small) sel = 14;
+  else if (pp_ok) {
     const int64_t c12 = cdiv(t12, 256) * 256, c13 = cdiv(t13, 256) * 288;     // rounds x rows per tile
     sel = (!a.transpose_out && a.epi == USDM_EPI_PLAIN && c13 < c12) ? 13 : 12;
   }
@@ -952,6 +959,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 11) return launch<bf16_t, 128, 128, 2, 2, true, 3, 2>(a, st);
     if (sel == 12) return launch<bf16_t, 256, 128, 4, 2, true, 3, 2, true>(a, st);   // 8-wave ping-pong loop, one workgroup per CU
     if (sel == 13) return launch<bf16_t, 288, 128, 2, 4, true, 3, 2, true>(a, st);   // row-major epilogues only
+    if (sel == 14) return launch<bf16_t, 128, 128, 4, 2, true, 3, 2, true>(a, st);   // the same loop on a 128x128 tile (wave tile 32x64)
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
         x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
         if (a.round_bf16) { x.x = round_bf(x.x); x.y = round_bf(x.y); x.z = round_bf(x.z); x.w = round_bf(x.w); }
       }
+      for (int e2 = 0; e2 < a.n_res2; ++e2) {              // further f32 addends (split-K partials of the producing GEMM), in order
+        const float4 r4 = *(const float4*)(a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr + idx * 4);
+        x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
+      }
       if (a.premask && zero_row) x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.sum32) *(float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4) = x;
       if (a.sum16) {
@@ -121,6 +125,7 @@ extern "C" int usdm_norm(const usdm_norm_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.rows > 0, "usdm_norm: rows");
   USDM_CHECK_ARG(a.out32 || a.out16, "usdm_norm: no output");
   USDM_CHECK_ARG(!a.valid_len || a.rows_per_batch > 0, "usdm_norm: rows_per_batch");
+  USDM_CHECK_ARG(a.n_res2 >= 0 && a.n_res2 <= 8 && (a.n_res2 == 0 || (a.res2 && a.res2_stride % 4 == 0 && !a.round_bf16)), "usdm_norm: res2");
   USDM_CHECK_ARG(a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.lds % 4 == 0, "usdm_norm: strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(a.rows, 4)), block(256);

@@ -103,7 +103,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
 
 def norm(x, gamma, beta=None, *, rows, C, eps=1e-5, res=None, rms=False, act=0, round_bf16=False, premask=False,
          valid_len=None, rows_per_batch=0, out32=None, out16=None, sum32=None, sum16=None,
-         ldx=None, ldr=None, ldo=None, lds=None, plan=None):
+         ldx=None, ldr=None, ldo=None, lds=None, res2=None, n_res2=0, res2_stride=0, plan=None):
     """usdm_norm: LayerNorm/RMSNorm over the last axis (see include/usdm_hip.h)."""
     _need_cuda(x, gamma, beta, res, out32, out16, sum32, sum16, valid_len)
     a = NormArgs()
@@ -115,6 +115,9 @@ def norm(x, gamma, beta=None, *, rows, C, eps=1e-5, res=None, rms=False, act=0, 
     a.valid_len, a.rows_per_batch = _ptr(valid_len), rows_per_batch
     a.out32, a.out16, a.ldo = _ptr(out32), _ptr(out16), (ldo if ldo is not None else C)
     a.sum32, a.sum16, a.lds = _ptr(sum32), _ptr(sum16), (lds if lds is not None else C)
+    if res2 is not None:     # further f32 addends (split-K partials): res2[i] for i < n_res2, res2_stride elements apart
+        _need_cuda(res2)
+        a.res2, a.n_res2, a.res2_stride = _ptr(res2), (n_res2 or 1), res2_stride
     _go(plan, "usdm_norm", lib.usdm_norm, C_.byref(a))
 
 

@@ -220,7 +220,8 @@ class Transformer(nn.Module):
 
         import os
         use_split = os.environ.get("USDM_VB_SPLITK", "1") == "1" and I >= 4 * H and R >= 1024
-        split2 = plan.hold(torch.zeros(2, R, H, device=dev, dtype=torch.float32)) if use_split else None
+        nsp = int(os.environ.get("USDM_VB_SPLITK_N", "3"))
+        split2 = plan.hold(torch.zeros(nsp, R, H, device=dev, dtype=torch.float32)) if use_split else None
 
         def layer(lp, cur, out16):
             ops.gemm(cur, lp["wqkv"], M=R, N=3 * H, Kc=H, bias=lp["bqkv"], plan=plan,
@@ -233,11 +234,12 @@ class Transformer(nn.Module):
             ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan, **mk)
             ops.gemm(pc16, lp["w1"], M=R, N=I, Kc=H, bias=lp["b1"], act=ACT_GELU, out16=f16, plan=plan)
             if split2 is not None:
-                # deep-K GEMM with only 18 x 8 output tiles of 128x128: two split-K partials (one round of 288 workgroups);
-                # the LayerNorm that follows sums them (its residual input)
-                ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=split2, split_k=2,
+                # deep-K GEMM with only 9 x 8 output tiles of 256x128: three split-K partials (one round of 216 workgroups);
+                # the LayerNorm that follows sums them (its residual inputs), in split order
+                ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=split2, split_k=nsp,
                          c_split_stride=R * H, plan=plan)
-                ops.norm(split2[0], *lp["ln2"], rows=R, C=H, res=split2[1], out32=h32, out16=out16, plan=plan, **mk)
+                ops.norm(split2[0], *lp["ln2"], rows=R, C=H, res=split2[1], out32=h32, out16=out16, plan=plan,
+                         **(dict(res2=split2[2], n_res2=nsp - 2, res2_stride=R * H) if nsp > 2 else {}), **mk)
             else:
                 ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=tmp32, plan=plan)
                 ops.norm(tmp32, *lp["ln2"], rows=R, C=H, out32=h32, out16=out16, plan=plan, **mk)
