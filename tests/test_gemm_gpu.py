@@ -289,6 +289,21 @@ def test_pingpong_tiles_bit_identical(dev, tile, tile_env):
     ref = (A.double().cpu().reshape(Bx, S1, K) @ W.double().cpu().T + b.double().cpu())
     _check(run(tile, batched)[0].reshape(Bx, S1 + 1, Nn)[:, 1:], ref, torch.bfloat16, K, "batched vs reference")
 
+    # two sources concatenated along K (the Voicebox skip Linear, networks.py:364): taps = 2, a_tap_stride, no row shift
+    Mm, Hh2 = 600, 256
+    buf = _rand((3, Mm, Hh2), torch.bfloat16, 43, 0.3).to(dev)
+    W2 = _rand((Hh2, 2 * Hh2), torch.bfloat16, 44, 0.3).to(dev)
+
+    def two_source():
+        o32 = torch.zeros((Mm, Hh2), device=dev); o16 = torch.zeros((Mm, Hh2), device=dev, dtype=torch.bfloat16)
+        ops.gemm(buf, W2, M=Mm, N=Hh2, Kc=Hh2, taps=2, lda=Hh2, rowsA=Mm, a_tap_stride=2 * Mm * Hh2, bias=b[:Hh2].contiguous(), out32=o32, out16=o16)
+        return o32, o16
+
+    for x, y in zip(run(4, two_source), run(tile, two_source)):    # (4 is routed to the register-staged tile for multi-tap operands)
+        assert torch.equal(x, y), f"two-source K: tile {tile} differs"
+    ref = torch.cat([buf[0].cpu(), buf[2].cpu()], -1).double() @ W2.double().cpu().T + b[:Hh2].double().cpu()
+    _check(run(tile, two_source)[0], ref, torch.bfloat16, 2 * Hh2, "two-source K vs reference")
+
     # head-split epilogue: two sequences whose boundary falls inside a tile at an even and at an odd position
     for S in (1118, 333):
         B, Hh, D, K = 2, 4, 64, 128

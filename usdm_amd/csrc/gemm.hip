@@ -310,11 +310,19 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     if constexpr (PP) {
       char* sAs = smem + slot * STAGE;
       char* sBs = sAs + BM * 128;
-      const unsigned kcol = (unsigned)((q_lo + 2 * step) * 64);
+      // source columns of the step: W is [N][taps * Kc]; A adds a_tap_stride per tap (operands concatenated along K from
+      // several sources: a_row_step == 0, Kc % 64 == 0, so a step never straddles two taps and the remap is one scalar division)
+      const int q = q_lo + 2 * step;
+      const unsigned kcolW = (unsigned)(q * 64);
+      unsigned kcolA = kcolW;
+      if (a.taps > 1) {
+        const int tap = q / cpt;
+        kcolA = (unsigned)(((int64_t)(q - tap * cpt) * CE + (int64_t)tap * a.a_tap_stride) * ES);
+      }
 #pragma unroll
       for (int i = 0; i < PNF; ++i) {
         if (part != 2 && (i < PNF / 2) != (part == 0)) continue;
-        unsigned off = pofs[i] + kcol;
+        unsigned off = pofs[i] + (i < PFA ? kcolA : kcolW);
         if (chk && ((phi >> i) & 1)) off = OOB;
         if (i < PFA)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (wv + NWV * i) * 1024), 16, off, 0, 0, 0);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBs + (wv + NWV * (i - PFA)) * 1024), 16, off, 0, 0, 0);
       }
       if (PLA && part != 0) {
-        unsigned off = pofs[PNF] + kcol;
+        unsigned off = pofs[PNF] + kcolA;
         if (chk && ((phi >> PNF) & 1)) off = OOB;
         if ((lane >> 5) == (wv & 1))
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (PFA * NWV + (wv >> 1)) * 1024), 16, off, 0, 0, 0);
@@ -918,12 +926,14 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   // Big single-tap bf16 GEMMs: the 8-wave ping-pong tiles (256x128, or 288x128 when that saves a round of workgroups) at one
   // workgroup per CU, 1.2-2x the 128x128 tile on the Voicebox and LLM-prefill shapes (profiles/r02_gemm_ablation.txt section 4)
   const int64_t t12 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 128) * z, t13 = (int64_t)cdiv(a.M, 288) * cdiv(a.N, 128) * z;
-  const bool pp_ok = heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 && t12 >= 96 && a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256 &&
+  const bool pp_taps = a.taps == 1 || (a.a_row_step == 0 && a.Kc % 64 == 0);      // single tap, or sources concatenated along K
+  const bool pp_ok = heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 && t12 >= 96 && a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256 &&
                      (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
   // ... and its 128x128 form where the big tiles would leave half the CUs idle (96-256 tiles of 128x128, one per CU)
   const int64_t t14 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   static const int pp14 = getenv("USDM_GEMM_PP_SMALL") ? atoi(getenv("USDM_GEMM_PP_SMALL")) : 1;
-  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 && t12 < 128 && t14 >= 96 && t14 <= 256 &&
+  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 &&   // (K-concatenated sources: measured no gain, 29 vs 30 us)
+                        t12 < 128 && t14 >= 96 && t14 <= 256 &&
                         a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256;
   if (pp_small) sel = 14;
   else if (pp_ok) {
@@ -945,7 +955,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
-  if (a.taps != 1 && sel >= 4) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
+  if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
