@@ -15,6 +15,10 @@
 //   * epilogue through LDS: the accumulator tile is transposed in LDS so that bias / activation /
 //     residual / rounding run on 4 consecutive outputs per thread and every global access is
 //     8-16 B wide (row-major, transposed, head-split QKV and SwiGLU layouts alike).
+//   * loader variants of the same kernel: register-staged (above), LDS-DMA with 2-4 stages, and - for the
+//     big single-tap bf16 GEMMs (Voicebox QKV / FFN, LLM prefill) - the 8-wave PING-PONG loop on 256x128,
+//     288x128 and 128x128 tiles at one workgroup per CU ("8-wave ping-pong loop" below; selection in
+//     usdm_gemm; measurements in profiles/r02_gemm_ablation.txt sections 3-4).
 #include "common.h"
 #include "../../include/usdm_hip.h"
 #include <stdlib.h>
@@ -856,6 +860,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   TR(5);
 #endif
 }
+
+#undef USDM_GEMM_FETCH_BIAS
 
 template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2, bool PP = false>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
