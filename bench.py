@@ -57,30 +57,42 @@ class Pipeline:
         # through torch.distributed as the fallback.  The transport is CHECKED on the real ranks before it is trusted
         # (usdm_amd.p2p.self_test): if the check fails on this node the bench falls back to RCCL and says so in its JSON line.
         self.tp_comm, comm = "none", None
+        tp_kw = dict(ctx_max=1536, tp_rank=rank, tp_size=world, group=group, tp_segments=True if (args.force_dist or world > 1) else None)
         if world > 1 or args.force_dist:
             self.tp_comm = "rccl"
             if os.environ.get("USDM_TP_COMM", "p2p") == "p2p":
-                import torch.distributed as dist
                 from usdm_amd.llm import MISTRAL_7B_USDM as C7
                 from usdm_amd.p2p import P2PComm, self_test
-                why, fused = None, True
-                try:
-                    fused = os.environ.get("USDM_P2P_FUSED", "1") == "1"
-                    probe = P2PComm.from_process_group(group, 3, 4096, timeout_ms=3000)
+                # Every step below ends in a verdict that is IDENTICAL on all ranks (usdm_amd.p2p.try_from_process_group / agree):
+                # no rank ever leaves the group's collective sequence on its own.
+                fused = os.environ.get("USDM_P2P_FUSED", "1") == "1"
+                probe, why = P2PComm.try_from_process_group(group, 3, 4096, timeout_ms=3000)
+                if probe is not None:
                     why = self_test(probe, group, dev, fused=fused)
                     probe.close()
-                except Exception as e:  # noqa: BLE001
-                    why = repr(e)
-                flag = torch.tensor([0 if why is None else 1], device="cpu" if dist.get_backend(group) == "gloo" else dev)
-                dist.all_reduce(flag, group=group)          # every rank must take the same decision
-                if int(flag.item()) == 0:
-                    comm = P2PComm.from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
-                    self.tp_comm = ("p2p (one-shot xGMI exchange fused into the row-parallel GEMV epilogues; self-test passed)" if fused else
-                                    "p2p, split form (put in the GEMV epilogue + reduce launch; self-test passed)")
-                else:
-                    self.tp_comm = f"rccl (p2p self-test failed on {int(flag.item())} rank(s): {why})"
-        self.llm = synth.make_llm(dev, ctx_max=1536, tp_rank=rank, tp_size=world, group=group,
-                                  tp_segments=True if (args.force_dist or world > 1) else None, p2p=comm)
+                if why is None:
+                    comm, why = P2PComm.try_from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
+                if why is not None:
+                    self.tp_comm = f"rccl (p2p start-up check failed: {why})"
+        self.llm = synth.make_llm(dev, p2p=comm, **tp_kw)
+        if comm is not None:
+            # in-situ check on the real model and the real ranks before the transport is trusted with the timed region: 24 greedy
+            # tokens; every rank must hold the SAME token stream (the exchange sums in rank order on every rank, so any
+            # difference means lost or stale partials) and a clean error word.  Otherwise: RCCL, same weights.
+            why = self._tp_crosscheck(group)
+            if why is None:
+                self.tp_comm = ("p2p (one-shot xGMI exchange fused into the row-parallel GEMV epilogues; start-up self-test and "
+                                "cross-rank token agreement passed on this node)" if fused else
+                                "p2p, split form (put in the GEMV epilogue + reduce launch; self-test and token agreement passed)")
+            else:
+                from usdm_amd.llm import USDMForCausalLM
+                W, old = self.llm.W, self.llm
+                self.llm = USDMForCausalLM(old.cfg, dev, p2p=None, **tp_kw)
+                self.llm.W = W
+                self.llm._alloc()
+                del old
+                comm.close()
+                self.tp_comm = f"rccl (p2p in-situ check failed: {why})"
         self.vb = synth.make_voicebox(dev)
         self.voc = synth.make_bigvgan(dev, compute_dtype=torch.float32 if args.vocoder_dtype == "f32" else torch.bfloat16)
         torch.cuda.synchronize()
@@ -101,6 +113,28 @@ class Pipeline:
         self.bad_t2t = generate_bad_words_ids(32002, 42003)
         self.bad_t2u = generate_bad_words_ids(0, 32002, exclude=[28705])
         self.ev = {}
+
+    def _tp_crosscheck(self, group, new_tokens=24):
+        """-> None if the p2p decode produced the same tokens on every rank with a clean error word, else the reason; the same
+        verdict on every rank (one object all-gather reached by all)."""
+        import torch.distributed as dist
+        from usdm_amd.p2p import agree
+        fail, toks = None, None
+        try:
+            ids = torch.randint(32002, 42002, (1, 96), generator=torch.Generator().manual_seed(7)).to(self.dev)
+            toks = self.llm.generate(input_ids=ids, max_new_tokens=new_tokens)[0, 96:].tolist()
+            err, _ = self.llm.p2p.status()
+            if err:
+                fail = f"error word {err:#x} after {new_tokens} tokens"
+        except Exception as e:  # noqa: BLE001 - recorded; the agreement below is still reached
+            fail = repr(e)
+        world = dist.get_world_size(group)
+        got = [None] * world
+        dist.all_gather_object(got, toks, group=group)
+        if fail is None and any(t != got[0] for t in got):
+            fail = "token streams differ between ranks"
+        self.llm._kv_ids = None
+        return agree(group, fail)
 
     def _mark(self, name):
         e = torch.cuda.Event(enable_timing=True)
@@ -252,7 +286,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, dev):
+def cpu_baseline(args, dev, pipe):
     """CPU oracle (kind 'port') on the host cores, as BASELINE.md section 4 states it: the FULL-size models (weights generated on the
     GPU and copied to the host), tokenizer and BigVGAN timed in full, the 7B over a 128-token prefill + 16 decode tokens and the
     Voicebox over 3 CFG-doubled NFEs, each scaled to the workload of one bench step.  About 30 s of CPU work."""
@@ -268,13 +302,13 @@ def cpu_baseline(args, dev):
         cfg = dict(WO.XLSR_1B)
         sd = {k: v.cpu() for k, v in synth.w2v_state_dict(dev).items()}
         cen = synth.w2v_centroids(dev).cpu()
-        wave = torch.randn(160000) * 0.1
+        wave = pipe.wave.detach().cpu()                   # the step's own input (identical inputs)
         t = time.time(); WO.kmeans_assign(WO.features(sd, cfg, wave, 34), cen); out["tokenizer_s"] = time.time() - t
         del sd, cen
         # BigVGAN, in full: 861 frames
         h = dict(BO.BIGVGAN_22K_80)
         sd = BO.random_state_dict(h, 0)
-        mel = torch.randn(1, 80, frames) * 2.1575 - 5.5419
+        mel = torch.randn(1, 80, frames, generator=torch.Generator().manual_seed(1)) * 2.1575 - 5.5419
         t = time.time(); BO.bigvgan_forward(sd, h, mel); out["bigvgan_s"] = time.time() - t
         del sd
         # Voicebox: 3 CFG-doubled NFEs at full depth and length (S = 256 + frames), scaled to the step's NFE count
@@ -297,7 +331,7 @@ def cpu_baseline(args, dev):
         for _ in range(16):
             _, cache = MO.forward(sd, cfg, ids[:1], cache)
         td = (time.time() - t) / 16
-        prompt_tokens = 548 + 586 + 619
+        prompt_tokens = int(sum(pipe.prompt_lens))       # the three prompts of the timed step (the reference re-prefills each round)
         n_gen = 2 * args.text_tokens + args.units
         out["llm_s"] = tp * prompt_tokens / 128 + td * n_gen
         out_tok = 1.0 / td
@@ -464,7 +498,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - informational field only, must never break the bench line
                 res["llm_batched_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args, dev)
+            res["cpu_baseline"] = cpu_baseline(args, dev, pipe)
     elif dist_on:
         measure_gemv_roofline(pipe.llm)  # collectives inside the TP decode need every rank
     if dist_on:

@@ -236,7 +236,8 @@ typedef struct usdm_gemv_args {
    * bf16(sum)): the all-reduce, the residual add and the bf16 rounding of HF's residual stream in one epilogue, no
    * collective launch.  p2p_mode 2 (split): write only; usdm_allreduce_p2p_reduce finishes.  Needs residual and y16. */
   const struct usdm_p2p_dev* p2p; int32_t p2p_site, p2p_mode;
-  /* o_proj of the decode step: x is not read from memory but MERGED here, in the x-staging prologue, from the context-split
+  /* EXPERIMENTAL, off by default (measured slower: profiles/r02_decode_ablation.txt section 1; see usdm_hip_experimental.h).
+   * o_proj of the decode step: x is not read from memory but MERGED here, in the x-staging prologue, from the context-split
    * partials usdm_attn_decode left (defer_merge): x[h*128+d] = bf16( sum_s po[h][s][d]*w_s / sum_s pl[h][s]*w_s ),
    * w_s = exp(pm[h][s] - max_s pm[h][s]).  Replaces the separate combine launch (the prologue runs while this launch's first
    * weight loads are in flight).  K = heads*128; mrg_ns splits per head. */
@@ -245,42 +246,6 @@ typedef struct usdm_gemv_args {
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
 
-/* Chained decode GEMVs in ONE persistent launch (round 2): up to 4 consecutive projections of the decode step, each consuming
- * the previous one's output vector (e.g. o_proj -> gate/up -> down_proj -> next layer's qkv), run by one resident grid.
- * Between two phases there is an all-to-all dependency (every workgroup needs the whole vector), i.e. a grid barrier; it is
- * hidden because the weights do not depend on the activations: every wave requests the first ring of its NEXT phase's weight
- * rows before it waits, so HBM keeps streaming across the phase boundary instead of draining and ramping up again as at a
- * launch boundary.  Per output row the arithmetic (lane partition of K, accumulation order, rounding points, RMSNorm / SwiGLU /
- * residual fusion) is that of usdm_gemv, bit for bit.
- *   ph[i]   : the usdm_gemv_args of phase i (plain or SwiGLU projections with y16 output; no lm_head / p2p / x_delta / merge
- *             modes; K a multiple of 512).  x of phase i+1 is normally y16 of phase i (or the residual stream it updated).
- *   sync    : 8 device words owned by the caller, zero-initialised once: [0] generation, [1] error, [2..4] arrival counters.
- *             Counters are monotonic (target = (generation + 1) * workgroups), so a captured hipGraph replays correctly
- *             without a memset node.
- *   Every wait is bounded (timeout_ms of the 100 MHz clock): on expiry the error word is set (USDM_CHAIN_ERR_TIMEOUT) and
- *   the kernel finishes with garbage instead of hanging; once set, later launches do not wait.  Needs all workgroups
- *   resident (2 x 448 threads per CU on the 256 CUs: nothing else may occupy the GPU for long). */
-enum { USDM_CHAIN_MAX_PHASES = 4, USDM_CHAIN_ERR_TIMEOUT = 1 };
-typedef struct usdm_gemv_chain_args {
-  usdm_gemv_args ph[4];
-  int32_t nph;
-  uint32_t* sync;
-  int32_t timeout_ms;
-  uint64_t* gran;   /* usdm_gemv_engine only: 3 x 8192 eight-byte granules of hand-off space (192 KB), any content */
-  int32_t norm_nth[4]; /* filled by the launcher: threads per workgroup of the usdm_gemv variant each phase would run with */
-} usdm_gemv_chain_args;
-int usdm_gemv_chain(const usdm_gemv_chain_args* args, usdm_stream_t stream);
-
-/* The same chain on a loader / consumer ENGINE (round 2, second form): one 4-wave workgroup per CU; wave 0 only streams the
- * CU's share of every phase's weight rows into a 7 x 16 KiB LDS ring by LDS-DMA (buffer_load ... lds, non-temporal), running
- * ahead across phase boundaries as far as the ring allows; waves 1-3 take ring slots (FULL / FREE words in LDS), multiply
- * against the phase's input vector held in LDS and publish each output pair twice: as plain bf16 (for later launches) and as
- * an 8-byte granule {tag = epoch, 2 x bf16} that every CU's gathering wave sweeps into its LDS copy of the next phase's input
- * (the data is its own flag: no grid barrier, no counter).  Per row the arithmetic - lane partition of K, accumulation order,
- * RMSNorm partial-sum order of the equivalent usdm_gemv launch, rounding points - is that of usdm_gemv, bit for bit.
- * Shapes: every phase's output count a multiple of 512; K = 4096 (any phase) or 16 < K/512 <= 32 with K/512 even (plain
- * phases, e.g. 14336).  sync: as usdm_gemv_chain ([0] generation, [1] error); all waits bounded. */
-int usdm_gemv_engine(const usdm_gemv_chain_args* args, usdm_stream_t stream);
 int usdm_gemv_threads(const usdm_gemv_args* args);   /* threads per workgroup usdm_gemv would launch this projection with */
 
 /* Batched decode: the same GEMV over nb <= 4 input vectors, weights streamed once per step.
@@ -387,14 +352,16 @@ int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
  *   parity  : epoch & 1 selects the half; together with the all-to-all of usdm_argmax_p2p once per token no slot is
  *             rewritten before every reader has left it
  *   waits   : every poll is BOUNDED (timeout_ms of the 100 MHz wall clock); on expiry the kernel ORs a code into the
- *             err word and carries on with zeros; once err != 0 no kernel waits again, so a protocol bug costs one
- *             timeout and surfaces as usdm_allreduce_p2p_error() != 0 - never as a hang
+ *             err word - its own AND every peer's (| USDM_P2P_ERR_PEER) - and carries on with zeros; once err != 0 no
+ *             kernel waits again, so a protocol bug costs one timeout and surfaces on EVERY rank as
+ *             usdm_allreduce_p2p_error() != 0 - never as a hang, never as silently diverging ranks
  *   order   : partials are summed in rank order 0..world-1 on every rank -> bit-identical results on all ranks
  * Host protocol: create -> export (64-byte hipIpcMemHandle) -> exchange handles by any host channel -> import each
  * peer (other process) or attach (same process, logical ranks) -> commit.  RCCL stays the prefill / validation path.
  * ---------------------------------------------------------------------------------------------- */
 enum { USDM_P2P_MAX_RANKS = 8, USDM_P2P_HANDLE_BYTES = 64, USDM_P2P_HEADER_BYTES = 256 };
-enum { USDM_P2P_ERR_TIMEOUT_ROWS = 1, USDM_P2P_ERR_TIMEOUT_PICK = 2, USDM_P2P_ERR_TIMEOUT_REDUCE = 4 };
+enum { USDM_P2P_ERR_TIMEOUT_ROWS = 1, USDM_P2P_ERR_TIMEOUT_PICK = 2, USDM_P2P_ERR_TIMEOUT_REDUCE = 4,
+       USDM_P2P_ERR_PEER = 8 /* set by ANOTHER rank that timed out (with its code): results may have diverged there */ };
 typedef struct usdm_p2p_dev {          /* device-visible view (device memory, constant after commit) */
   uint64_t base[8];                    /* address of rank r's buffer as mapped in THIS process; base[rank] = local */
   int32_t rank, world, n_sites, max_elems;

@@ -42,26 +42,42 @@ def test_dead_graph_in_a_cycle_is_collected_before_capture_and_gc_stays_off_insi
     ref = weakref.ref(dead.graph)
     gc.collect()
     old = gc.get_threshold()
-    gc.disable()                                   # keep it alive until the capture below...
+    gc.disable()                                   # keep it alive until the capture below (re-enabled at the end of step 2)
     del dead, plan
-    gc.enable()
     assert ref() is not None
 
-    # 2. capture another plan with the collector set to fire on every container allocation
+    # 2. the pre-capture collection of _no_gc() is what frees it: the test keeps the collector OFF through the eager run and up to
+    # the capture, so nothing else can have collected the dead graph before _no_gc() runs
     seen = []
     plan2, a2, b2 = make(8192)
     plan2.add("probe", lambda st: (seen.append((gc.isenabled(), ref() is None)), 0)[1])    # runs INSIDE the captured region
     live = GraphedPlan(plan2)
-    gc.set_threshold(1, 1, 1)
     try:
         live.run()                                 # eager
-        live.run()                                 # capture (would collect `dead` mid-capture without the guard -> abort)
+        assert ref() is not None, "the dead graph must still be pending when the capture is about to open"
+        assert seen[-1] == (False, False)
+        live.run()                                 # capture: _no_gc() collects first (legal), then opens the capture
+    finally:
+        gc.enable()
+    assert live.graph is not None
+    assert seen[-1] == (False, True), seen[-1]     # the dead graph was gone before the first captured launch
+    assert ref() is None
+
+    # 3. the collector stays off inside a capture even when it is set to fire on every container allocation
+    seen3 = []
+    plan3, a3, b3 = make(2048)
+    plan3.add("probe", lambda st: (seen3.append(gc.isenabled()), 0)[1])
+    live3 = GraphedPlan(plan3)
+    gc.set_threshold(1, 1, 1)
+    try:
+        live3.run()
+        assert seen3[-1] is True                   # eager run: collector on
+        live3.run()                                # capture
     finally:
         gc.set_threshold(*old)
-    assert live.graph is not None
-    inside = seen[-1]
-    assert inside == (False, True), inside         # collector off inside the capture; the dead graph was already gone
+    assert live3.graph is not None and seen3[-1] is False
     assert gc.isenabled()
     live.run()
+    live3.run()
     torch.cuda.synchronize()
-    assert torch.equal(a2, b2)
+    assert torch.equal(a2, b2) and torch.equal(a3, b3)

@@ -192,4 +192,8 @@ def test_p2p_missing_peer_times_out_with_error_word_not_a_hang(dev):
     assert time.time() - t0 < 0.15
     with pytest.raises(P2PError):
         comms[0].raise_if_failed()
-    assert comms[1].status() == (0, 1)
+    # the rank that timed out told its peer: rank 1 raises at ITS next host sync too, instead of carrying on with
+    # results that no longer match rank 0's (which substituted zeros for the partials it never received)
+    assert comms[1].status() == (1 | 8, 1)          # USDM_P2P_ERR_TIMEOUT_ROWS | USDM_P2P_ERR_PEER
+    with pytest.raises(P2PError):
+        comms[1].raise_if_failed()

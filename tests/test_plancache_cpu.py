@@ -43,3 +43,23 @@ def test_arena_replays_the_same_buffers_and_rezeroes_on_owner_switch():
     a.begin()
     q = a.zeros(100, 4)
     assert q.numel() == 400 and a.nbytes() > n0
+
+
+def test_arena_keeps_replaced_buffers_alive_and_zeroes_them_too():
+    """plans record raw pointers, so a buffer that a later, larger (or other-dtype) build replaces must stay alive -
+    and be restored to all-zero on an owner switch - for as long as the arena lives."""
+    a = Arena("cpu")
+    a.begin()
+    small = a.zeros(4, 4)
+    ptr = small.data_ptr()
+    a.begin()
+    big = a.zeros(64, 4)                       # does not fit the 16-element reservation -> replaces it
+    assert big.data_ptr() != ptr and len(a.retired) == 1 and a.retired[0].data_ptr() == ptr
+    a.begin()
+    other = a.zeros(8, dtype=torch.int64)      # another dtype in the same position -> replaces again
+    assert len(a.retired) == 2
+    a.take("p1")
+    small.fill_(3.0); big.fill_(2.0)
+    a.take("p2")
+    assert float(small.sum()) == 0.0 and float(big.sum()) == 0.0 and int(other.sum()) == 0
+    assert a.nbytes() == (16 + 256) * 4 + 8 * 8

@@ -94,6 +94,39 @@ def test_continuous_batching_vs_oracle(dev):
     assert st["batched_steps"] < sum(max_new)                                                      # steps were shared between sequences
 
 
+def test_batched_request_running_into_the_context_limit(dev):
+    """the reference passes max_tokens = tokenizer.model_max_length, so a greedy sequence that never emits its stop id
+    decodes up to the context limit.  In a continuous batch it must stop AT the limit (never append cache rows >= ctx_max, which
+    would be another head's / slot's rows) while its neighbours keep decoding and a queued request takes over its slot."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    from usdm_amd.serving import LLM, SamplingParams
+    sd = MO.random_state_dict(SMALL, seed=47)
+    m = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128)
+    eng = LLM(model=m)
+    g = torch.Generator().manual_seed(5)
+    lens = (101, 20, 99, 33, 25)                      # slots 0 and 2 hit the limit (27 / 29 tokens of room) at different steps
+    want = (100000, 70, 100000, 60, 50)               # what the caller asks for (model_max_length-style for the long prompts)
+    prompts = [torch.randint(0, 1000, (L,), generator=g) for L in lens]
+    sps = [SamplingParams(max_tokens=w, top_k=1) for w in want]
+    outs = eng.generate(prompt_token_ids=[p.tolist() for p in prompts], sampling_params=sps)
+    for p, w, o in zip(prompts, want, outs):
+        n = min(w, 128 - p.numel())
+        ref, ref_logits = MO.greedy_generate(sd, SMALL, p, n, return_logits=True)
+        toks = o.outputs[0].token_ids
+        check_against_oracle(p.tolist() + toks, ref, ref_logits, p.numel())
+        assert len(toks) == n and o.outputs[0].finish_reason == "length"
+    assert eng.stats["batched_requests"] == 5 and eng.stats["max_active"] == 4
+    # the guard inside usdm_attn_decode: a position at / past the end of the cache appends nothing and reads nothing out of range
+    bb = m._batch_buffers(4)
+    before = bb["kc"].clone()
+    bb["pos"].fill_(128); bb["step"].zero_()
+    bb["decode"].run()
+    torch.cuda.synchronize()
+    assert torch.equal(before, bb["kc"])
+
+
 def test_history_dependent_processor_and_sampling(dev):
     from oracle import mistral_oracle as MO
     from usdm_amd.llm import USDMForCausalLM

@@ -150,3 +150,53 @@ def test_tp2_gloo_gather_of_partials_with_uneven_vocab_split():
     for p in procs:
         p.join(30)
     assert all(r[1] for r in res), res
+
+
+def _p2p_wiring_worker(rank, world, port, out_q):
+    """a rank whose transport is broken must not leave the group's collective sequence on its own."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from usdm_amd import p2p as P
+    # 1. no GPU here: creating the exchange buffer fails on EVERY rank -> the same (None, reason) on every rank
+    c, why = P.P2PComm.try_from_process_group(dist.group.WORLD, 3, 64)
+    r1 = (c is None, "create/export" in (why or ""))
+    # 2. uneven failure: rank 0's wiring "works" (stand-ins for the HIP calls), rank 1's import raises
+    class Fake(P.P2PComm):
+        def __init__(self, rank, world, n_sites, max_elems, timeout_ms=None):
+            self.rank, self.world, self._h, self.closed = rank, world, None, False
+        def export_handle(self):
+            return b"h%d" % self.rank
+        def import_handle(self, peer, handle):
+            if self.rank == 1:
+                raise RuntimeError("hipIpcOpenMemHandle: invalid argument")
+        def commit(self):
+            pass
+        def close(self):
+            self.closed = True
+    c2, why2 = Fake.try_from_process_group(dist.group.WORLD, 3, 64)
+    r2 = (c2 is None, "rank 1: import/commit" in (why2 or ""))
+    with pytest.raises(P.P2PError):
+        Fake.from_process_group(dist.group.WORLD, 3, 64)
+    # 3. agree(): one rank's failure becomes everybody's verdict
+    v = P.agree(dist.group.WORLD, "boom" if rank == 1 else None)
+    r3 = v == "rank 1: boom"
+    # 4. the group is still in step: a plain collective after all of the above completes with the right value
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)
+    out_q.put((rank, r1, r2, r3, float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_p2p_wiring_failures_keep_every_rank_in_the_collective_sequence():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_wiring_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    for rank, r1, r2, r3, tot in res:
+        assert r1 == (True, True) and r2 == (True, True) and r3 and tot == 3.0, res

@@ -29,7 +29,7 @@ def _stale(obj, src):
         return True
     t = os.path.getmtime(obj)
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(HERE, "..", "include", "usdm_hip.h"))
+    deps += [os.path.join(HERE, "..", "include", h) for h in ("usdm_hip.h", "usdm_hip_experimental.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

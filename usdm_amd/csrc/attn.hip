@@ -232,7 +232,10 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
     // softmax denominator that is >= 1 (no change in f32) and < 2^-40 |v| per key to the output: its exponentials and its
     // P.V MFMAs are skipped.  With ALiBi (networks.py:319-341: slope 2^-(h+1)/2 per key of distance, key 0 unbiased) that is
     // most far tiles of the steep heads; fully masked tiles (bucket padding, scores -1e30) drop out the same way.
-    const bool skip_tile = __all(mloc < m_run - 40.0f);
+    // Causal mode (LLM prefill) skips FULLY MASKED tiles only, which is exact (p = 0, alpha = 1): whether a row's 2^-40-scale
+    // terms are dropped would otherwise depend on its wave-mates, and the exact prefix reuse of the LLM promises rows that do
+    // not depend on how many tokens were prefilled with them.
+    const bool skip_tile = MODE == 0 ? __all(mloc < m_run - 40.0f) : __all(mloc < -1e29f);
     if (!skip_tile) {
     const float m_new = fmaxf(m_run, mloc);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);

@@ -1,4 +1,4 @@
-// Chained decode GEMVs in one persistent launch (include/usdm_hip.h, usdm_gemv_chain).
+// Chained decode GEMVs in one persistent launch (include/usdm_hip_experimental.h, usdm_gemv_chain).
 //
 // Why: a batch-1 decode GEMV is pure weight streaming, and at every launch boundary HBM drains and ramps up again (~2.6 us of
 // dispatch + drain and ~4.6 us until the first ring of loads has arrived, profiles/r01_decode_ablation.txt).  The weights do not
@@ -12,7 +12,7 @@
 // (sc1) stores, every storing wave drains them, ONE lane adds to the arrival counter; consumers poll the counter (bounded) and read
 // the handed-off vectors only with agent-scope loads.
 #include "common.h"
-#include "../../include/usdm_hip.h"
+#include "../../include/usdm_hip_experimental.h"
 
 namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

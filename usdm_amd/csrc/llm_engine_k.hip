@@ -1,4 +1,4 @@
-// Loader / consumer engine for chained decode projections (include/usdm_hip.h, usdm_gemv_engine).
+// Loader / consumer engine for chained decode projections (include/usdm_hip_experimental.h, usdm_gemv_engine).
 //
 // One 8-wave workgroup per CU (256 workgroups, 157 KB of LDS each, so exactly one is resident per CU); NL loader waves and NC
 // consumer waves (4 + 4):
@@ -19,7 +19,7 @@
 // Per output row the arithmetic is usdm_gemv's, bit for bit (lane l owns 16-byte pieces l, l + 64, ... of K and accumulates them
 // in order; the RMSNorm partial sums follow the thread partition of the usdm_gemv variant that would run the projection).
 #include "common.h"
-#include "../../include/usdm_hip.h"
+#include "../../include/usdm_hip_experimental.h"
 
 namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

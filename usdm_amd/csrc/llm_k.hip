@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   const int bi = blockIdx.z;                      // sequence of a batched decode step (0 when single)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = a.pos[bi];
+  if ((unsigned)pos >= (unsigned)a.ctx_max) return;   // never append past the cache / rope table (a caller bug: the host bounds every sequence)
   const int ctx = pos + 1;
   const int chunk = (ctx + NS - 1) / NS;
   const int k0 = sp * chunk, k1 = min(ctx, k0 + chunk);
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const usdm_attn_deco
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   float* sc = (float*)dsm;                          // [G][ctx_pad]
   const int pos = *a.pos;
+  if ((unsigned)pos >= (unsigned)a.ctx_max) return;
   const int ctx = pos + 1;
   const int ctx_pad = (a.ctx_max + 3) & ~3;
   float* red = sc + G * ctx_pad;                    // [16][G][128]

@@ -45,6 +45,15 @@ __device__ __forceinline__ unsigned p2p_get_bits(const usdm_p2p_dev* d, p2p_gran
     if ((spins & 63) == 63) {
       if (wall_clock64() - t0 > d->timeout_ticks) {   // give up: flag the failure, later kernels do not wait again
         if (!ok) __hip_atomic_fetch_or(p2p_err_word(d), err_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and tell every peer (one lane of the wave, one system-scope OR per peer): a rank that timed out carries on with
+        // zeros for what it missed, so its token stream may diverge; with the word set everywhere ALL ranks raise at their
+        // next host sync instead of only this one
+        const unsigned long long fm = __ballot(!ok);
+        if (fm != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)fm) - 1) {
+          for (int r = 0; r < d->world; ++r)
+            if (r != d->rank)
+              __hip_atomic_fetch_or((unsigned*)d->base[r] + 1, err_code | USDM_P2P_ERR_PEER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
     }

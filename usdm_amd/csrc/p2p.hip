@@ -39,7 +39,10 @@ extern "C" int usdm_allreduce_p2p_create(int32_t rank, int32_t world, int32_t n_
     (void)hipFree(c->local); free(c); return 1;
   }
   const unsigned one = 1;   // epoch starts at 1: a zero-initialised tag never matches
-  if (hipMemcpy(c->local, &one, 4, hipMemcpyHostToDevice) != hipSuccess) { usdm_set_error("usdm_allreduce_p2p_create: epoch init failed"); return 1; }
+  if (hipMemcpy(c->local, &one, 4, hipMemcpyHostToDevice) != hipSuccess) {
+    usdm_set_error("usdm_allreduce_p2p_create: epoch init failed");
+    (void)hipFree(c->dev_view); (void)hipFree(c->local); free(c); return 1;
+  }
   c->peer[rank] = c->local;
   memset(&c->host_view, 0, sizeof(c->host_view));
   c->host_view.rank = rank; c->host_view.world = world; c->host_view.n_sites = n_sites; c->host_view.max_elems = max_elems;

@@ -54,18 +54,48 @@ class P2PComm:
 
     @classmethod
     def from_process_group(cls, group, n_sites, max_elems, timeout_ms=None):
-        """One rank per process: exchange the hipIpc handles over `group` and map every peer."""
+        """One rank per process: exchange the hipIpc handles over `group` and map every peer.  Raises P2PError on EVERY rank
+        if any rank failed (see try_from_process_group): the ranks never leave the group's collective sequence one by one."""
+        c, why = cls.try_from_process_group(group, n_sites, max_elems, timeout_ms)
+        if c is None:
+            raise P2PError(f"peer-to-peer communicator could not be wired: {why}")
+        return c
+
+    @classmethod
+    def try_from_process_group(cls, group, n_sites, max_elems, timeout_ms=None):
+        """-> (comm, None) on every rank, or (None, reason) on every rank.  A local failure (hipMalloc, hipIpcGetMemHandle,
+        hipIpcOpenMemHandle of one peer, ...) is RECORDED, not raised: every rank runs the same two object all-gathers, learns
+        whether all ranks succeeded, and only then do they all keep or all drop the transport (a rank that leaves
+        the collective sequence early leaves its peers in mismatched collectives - a hang or garbage under RCCL)."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        c = cls(rank, world, n_sites, max_elems, timeout_ms)
+        c, handle, err = None, None, None
+        try:
+            c = cls(rank, world, n_sites, max_elems, timeout_ms)
+            handle = c.export_handle()
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {rank}: create/export: {e!r}"
         handles = [None] * world
-        dist.all_gather_object(handles, c.export_handle(), group=group)
-        for r in range(world):
-            if r != rank:
-                c.import_handle(r, handles[r])
-        c.commit()
+        dist.all_gather_object(handles, handle, group=group)
+        if err is None and all(h is not None for h in handles):
+            try:
+                for r in range(world):
+                    if r != rank:
+                        c.import_handle(r, handles[r])
+                c.commit()
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {rank}: import/commit: {e!r}"
+        elif err is None:
+            err = f"rank {rank}: peer(s) {[r for r, h in enumerate(handles) if h is None]} exported no handle"
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        bad = [e for e in errs if e is not None]
+        if bad:
+            if c is not None:
+                c.close()
+            return None, "; ".join(bad)
         dist.barrier(group=group)      # every rank has mapped every buffer before anybody writes
-        return c
+        return c, None
 
     @classmethod
     def in_process(cls, world, n_sites, max_elems, timeout_ms=None):
@@ -171,35 +201,66 @@ class InProcessGroup:
             self._pend = []
 
 
+def agree(group, local_failure):
+    """Every rank contributes its first local failure (a string) or None; every rank gets the same verdict back: None if all
+    are None, else the failures joined.  One object all-gather, reached by every rank whatever happened before."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    got = [None] * world
+    dist.all_gather_object(got, local_failure, group=group)
+    bad = [f"rank {r}: {m}" for r, m in enumerate(got) if m is not None]
+    return "; ".join(bad) if bad else None
+
+
 def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
     """Start-up check of a freshly wired communicator across the REAL ranks of `group`: `rounds` fused all-reduces (the GEMV
     epilogue form, both parities) checked against the group's own all_reduce of the same f32 partials, and `rounds` cross-rank
     token picks checked against the known winner.  The default shape is the o_proj shard of the 7B at TP = 8 (4096 outputs: the
     256-workgroup, 16-wave launch the decode step uses), so that a node on which those grids cannot make progress fails HERE.
-    fused=False checks the split form (put in the epilogue + usdm_allreduce_p2p_reduce).  Returns None if everything matches,
-    else a description of what failed (callers fall back to the RCCL path)."""
+    fused=False checks the split form (put in the epilogue + usdm_allreduce_p2p_reduce).
+    Returns the SAME verdict on every rank: None if everything matched everywhere, else a description of what failed where
+    (callers fall back to the RCCL path).  A rank that sees a timeout, a mismatch or an exception records it and KEEPS GOING:
+    every rank executes every round's group collective and the final agreement, so the collective sequence on the group can
+    never get out of step because one rank's transport is broken."""
     import torch
     import torch.distributed as dist
     from . import ops
+    fail = None
+
+    def note(msg):
+        nonlocal fail
+        if fail is None:
+            fail = msg
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo"
+    ep0 = 0
     try:
         if comm.n_sites < 2:
-            return "self-test needs at least two sites (rows + token pick)"
-        rank, world = comm.rank, comm.world
+            note("self-test needs at least two sites (rows + token pick)")
         _, ep0 = comm.status()
-        staged = dist.get_backend(group) == "gloo"
-        g = torch.Generator().manual_seed(1000 + rank)
-        gs = torch.Generator().manual_seed(999)          # shared by all ranks
-        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)
-        for it in range(rounds):
-            W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
-            x = torch.randn(K, generator=g).to(torch.bfloat16).to(device)
-            h0 = torch.randn(N, generator=gs).to(torch.bfloat16).to(device)
-            part = torch.zeros(N, dtype=torch.float32, device=device)
+    except Exception as e:  # noqa: BLE001
+        note(f"status raised {e!r}")
+    g = torch.Generator().manual_seed(1000 + rank)
+    gs = torch.Generator().manual_seed(999)          # shared by all ranks
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=device)
+    for it in range(rounds):
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+        x = torch.randn(K, generator=g).to(torch.bfloat16).to(device)
+        h0 = torch.randn(N, generator=gs).to(torch.bfloat16).to(device)
+        part = torch.zeros(N, dtype=torch.float32, device=device)
+        try:
             ops.gemv(W, x, N=N, K=K, round_bf16=False, y32=part)
-            if staged:
-                c = part.cpu(); dist.all_reduce(c, group=group); tot = c.to(device)
-            else:
-                tot = part.clone(); dist.all_reduce(tot, group=group)
+        except Exception as e:  # noqa: BLE001
+            note(f"round {it}: gemv raised {e!r}")
+        # the group's own collective: ALWAYS executed, by every rank, in every round
+        if staged:
+            c = part.cpu(); dist.all_reduce(c, group=group); tot = c.to(device)
+        else:
+            tot = part.clone(); dist.all_reduce(tot, group=group)
+        if fail is not None and "needs at least two sites" in fail:
+            continue
+        try:
             want = (h0.float() + tot.to(torch.bfloat16).float()).to(torch.bfloat16)
             h = h0.clone()
             site = it % (comm.n_sites - 1)            # (the last site is the token pick's)
@@ -209,11 +270,11 @@ def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
             torch.cuda.synchronize()
             err, _ = comm.status()
             if err:
-                return f"round {it}: exchange timed out (error word {err:#x})"
+                note(f"round {it}: exchange timed out (error word {err:#x})")
             diff = (h.float() - want.float()).abs()
             ulp = want.float().abs().clamp_min(1e-3) * 2 ** -7
             if bool((diff > 2 * ulp).any()) or float((diff == 0).float().mean()) < 0.98:
-                return f"round {it}: all-reduce result differs from the group's all_reduce (max diff {float(diff.max()):.3e})"
+                note(f"round {it}: all-reduce result differs from the group's all_reduce (max diff {float(diff.max()):.3e})")
             # token pick: rank (it % world) holds the winner
             pv = torch.full((4,), -1.0 - rank, device=device)
             pi = torch.arange(4, dtype=torch.int32, device=device) + 100 * rank
@@ -224,10 +285,13 @@ def self_test(comm, group, device, rounds=4, N=4096, K=512, fused=True):
             ops.argmax_p2p(pv, pi, 4, st, comm, comm.n_sites - 1, phase=0)
             torch.cuda.synchronize()
             if int(nxt.item()) != 100 * (it % world) + 2:
-                return f"round {it}: cross-rank token pick returned {int(nxt.item())}"
+                note(f"round {it}: cross-rank token pick returned {int(nxt.item())}")
+        except Exception as e:  # noqa: BLE001 - recorded; the remaining rounds' collectives still run
+            note(f"round {it}: raised {e!r}")
+    try:
         err, ep = comm.status()
         if err or ep != ep0 + rounds:
-            return f"status after self-test: error word {err:#x}, epoch {ep} (expected {ep0 + rounds})"
-        return None
-    except Exception as e:  # noqa: BLE001 - any failure means: do not use this transport
-        return f"self-test raised {e!r}"
+            note(f"status after self-test: error word {err:#x}, epoch {ep} (expected {ep0 + rounds})")
+    except Exception as e:  # noqa: BLE001
+        note(f"status raised {e!r}")
+    return agree(group, fail)

@@ -71,6 +71,7 @@ class Arena:
 
     def __init__(self, device):
         self.device, self.bufs, self.i, self.owner = device, [], 0, None
+        self.retired = []     # buffers a later build replaced: earlier plans hold raw POINTERS into them, so they stay alive here
 
     def begin(self):
         self.i = 0
@@ -85,7 +86,10 @@ class Arena:
         else:
             b = torch.zeros(max(n, 1), dtype=dtype, device=self.device)
             if self.i < len(self.bufs):
-                self.bufs[self.i] = b       # (a build that asks for more than the reservation: the old buffer stays with its plans)
+                # a build that asks for more than the reservation (or another dtype): plans built before keep replaying on the old
+                # buffer through the raw pointers in their argument structs, so the arena keeps it alive (and zeroes it in take())
+                self.retired.append(self.bufs[self.i])
+                self.bufs[self.i] = b
             else:
                 self.bufs.append(b)
         self.i += 1
@@ -95,9 +99,9 @@ class Arena:
         """Called before a plan runs: a different plan used the workspace last -> restore the all-zero initial condition."""
         if self.owner is not owner:
             if self.owner is not None:
-                for b in self.bufs:
+                for b in self.bufs + self.retired:
                     b.zero_()
             self.owner = owner
 
     def nbytes(self):
-        return sum(b.numel() * b.element_size() for b in self.bufs)
+        return sum(b.numel() * b.element_size() for b in self.bufs + self.retired)

@@ -250,7 +250,11 @@ class LLM:
             if not need or (freed and queue):
                 continue                                             # refill the freed slot(s) before spending more steps
             live = [b for b in range(MAX_SLOTS) if slots[b] is not None]
-            n = min(CHUNK, max(slots[b]["r"]["max_new"] - slots[b]["produced"] for b in live))
+            # never more steps than the slot with the FEWEST tokens left: batch slots have no device-side `done` word, so a
+            # slot would otherwise keep decoding to the end of the chunk - past its max_new, and for a request that runs to the
+            # context limit (the reference passes max_tokens = model_max_length) past ctx_max, i.e. into the next head's / the
+            # next slot's cache rows.  usdm_attn_decode additionally refuses positions >= ctx_max.
+            n = min(CHUNK, min(slots[b]["r"]["max_new"] - slots[b]["produced"] for b in live))
             for _ in range(n):
                 bb["decode"].run()
             self.stats["batched_steps"] += n

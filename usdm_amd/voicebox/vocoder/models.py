@@ -408,7 +408,7 @@ class BigVGAN(nn.Module):
             if Tb != T:
                 self._build_plan(Tb, dev, a)      # reserve the workspace at the bucket's capacity
             return a, LRU(MAX_PLANS)
-        arena, plans = self._plans.get_or_build((Tb, dev.index), new_arena)
+        arena, plans = self._plans.get_or_build((Tb, dev.index, self.compute_dtype), new_arena)
 
         def new_plan():
             plan, io = self._build_plan(T, dev, arena)
