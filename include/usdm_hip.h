@@ -168,9 +168,16 @@ typedef struct usdm_vb_input_args {
   const float* cond;   /* [B_in][F][S] */
   const void* table;   /* bf16 [n_tokens+1][E], already multiplied by sqrt(E) */
   int32_t B_in, dup, S, E, F, null_id, use_cond;
-  void* out; int64_t ldo; /* bf16 [B_in*dup][S][ldo] */
+  void* out; int64_t ldo; /* [B_in*dup][S][ldo] of out_dtype */
+  int32_t out_dtype;      /* USDM_BF16 (default plan: MFMA operand rows, table bf16) or USDM_F32 (exact-f32 plan: table f32) */
 } usdm_vb_input_args;
 int usdm_vb_build_input(const usdm_vb_input_args* args, usdm_stream_t stream);
+
+/* Attention probabilities of the exact-f32 Voicebox plan (the reference runs fp32: networks.py:162-210): in place on the f32 score
+ * matrix x[row][h*ldseg + j] = q_i.k_j (row = b*rows_per_batch + i): p = softmax_j(x - slopes[h]*|i-j|, key 0 unbiased when
+ * col0_zero) over keys j < kv_len[b]; masked keys -> 0, pad columns [n, npad) -> 0 (networks.py:319-341). */
+int usdm_softmax_alibi(float* x, int32_t rows, int32_t rows_per_batch, int32_t nheads, int32_t n, int32_t npad, int64_t ldrow,
+                       int32_t ldseg, const float* slopes, const int32_t* kv_len, int32_t col0_zero, usdm_stream_t stream);
 
 /* Sinusoidal time token (SinusoidalPosEmb, networks.py:13-28) into row 0 of each batch of h:
  * [sin(1000*t*freqs), cos(1000*t*freqs)], freqs[H/2] = exp(arange(H/2) * -ln(1e4)/(H/2-1)) from the host. */

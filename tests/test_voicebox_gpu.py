@@ -94,3 +94,43 @@ def test_voicebox_ragged_batch_estimator(dev):
     # a full-length call right after re-uses a different (non-ragged) plan
     full = m.estimator(d["x"].to(dev), d["y"].to(dev), d["cond"].to(dev), d["t"].to(dev), torch.tensor([52, 52]).to(dev))
     assert full[1, :, 33:].abs().max().item() > 0
+
+
+def test_voicebox_exact_f32_plan_vs_reference_goldens(dev):
+    """The exact-f32 plan (compute_dtype=torch.float32: f32 MFMA GEMMs, f32 attention probabilities) against the SAME reference
+    golden vectors at the f32-kernel tolerance of SURVEY.md 8d (1e-4 relative): small Heun+CFG+prompt generate, the ragged batch,
+    and the full-width CFG-doubled estimator.  The bf16 plan's numbers are printed beside it: the measured trade."""
+    from oracle import voicebox_oracle as VO
+    from tests.golden.configs import SMALL_VB
+    to = lambda t: t.to(dev)
+    d = _ld("voicebox_small.npz")
+    m = _model(SMALL_VB, int(d["seed"]), dev)
+    kw = dict(n_timesteps=int(d["nt_h"]), solver="heun", gradient_scale=1.0, speech_prompt=True,
+              prompt_lengths=torch.tensor([int(d["P"])]).to(dev), noise=d["noise_h"])
+    res = {}
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        m.estimator.set_compute_dtype(dt)
+        est = m.estimator(to(d["x"]), to(d["y"]), to(d["cond"]), to(d["t"]), to(d["lengths"]))
+        gen = m.generate(to(d["x"]), to(d["cond"]), to(d["lengths"]), **kw)
+        res[name] = (_rel(est, d["est"]), _rel(gen, d["gen_h"]))
+    print("small model, estimator / Heun+CFG+prompt generate rel L2:", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in res.items()})
+    assert res["f32"][0] <= 1e-4 and res["f32"][1] <= 1e-4 and res["bf16"][0] <= 1e-2 and res["bf16"][1] <= 3e-2
+    # ragged batch through the f32 plan (padding masks of networks.py:314-341)
+    d = _ld("voicebox_ragged.npz")
+    m = _model(SMALL_VB, int(d["seed"]), dev)
+    m.estimator.set_compute_dtype(torch.float32)
+    est = m.estimator(d["x"].to(dev), d["y"].to(dev), d["cond"].to(dev), d["t"].to(dev), d["lengths"].to(dev))
+    r = _rel(est, d["est"])
+    print("ragged estimator, f32 plan: rel L2 %.2e" % r)
+    assert r <= 1e-4 and est[1, :, 33:].abs().max().item() == 0.0
+    # full width
+    d = _ld("voicebox_full.npz")
+    m = _model(VO.VOICEBOX_CFG, int(d["seed"]), dev)
+    m.estimator.set_compute_dtype(torch.float32)
+    S = d["y"].shape[-1]
+    y2 = torch.cat([d["y"]] * 2)
+    c2 = torch.cat([torch.zeros_like(d["cond"]), d["cond"]])
+    est = m.estimator(d["x"].to(dev), y2.to(dev), c2.to(dev), torch.full((2, 1, 1), float(d["t"])).to(dev), torch.tensor([S, S]).to(dev))
+    r = _rel(est, d["est"])
+    print("full-width estimator, f32 plan: rel L2 %.2e" % r)
+    assert r <= 1e-4

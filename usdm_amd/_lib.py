@@ -88,7 +88,7 @@ class VbInputArgs(C.Structure):
         ("ids", C.c_void_p), ("y", C.c_void_p), ("cond", C.c_void_p), ("table", C.c_void_p),
         ("B_in", C.c_int32), ("dup", C.c_int32), ("S", C.c_int32), ("E", C.c_int32), ("F", C.c_int32),
         ("null_id", C.c_int32), ("use_cond", C.c_int32),
-        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
     ]
 
 

@@ -7,20 +7,52 @@ namespace {
 // A[bx][s][0:E] = table[id] (pre-scaled by sqrt(E) at pack time), [E:E+F] = y[:, s], [E+F:E+2F] = cond[:, s]
 // (networks.py:305-307).  dup == 2 is the classifier-free-guidance doubling of voicebox.py:60-65:
 // the first B_in rows of the batch are the unconditional copy (null token, zero cond).
+template <typename OT>   // OT = bf16_t (MFMA-operand rows of the default plan) or float (the exact-f32 plan; table is f32 then)
 __global__ void vb_build_input_kernel(const usdm_vb_input_args a) {
   const int s = blockIdx.x, bx = blockIdx.y;
   const int b = bx % a.B_in, half = bx / a.B_in;
   const bool uncond = (a.dup == 2) && (half == 0);
   const int64_t id = uncond ? (int64_t)a.null_id : a.ids[(int64_t)b * a.S + s];
-  bf16_t* out = (bf16_t*)a.out + ((int64_t)bx * a.S + s) * a.ldo;
-  const bf16_t* row = (const bf16_t*)a.table + id * a.E;
-  for (int c = threadIdx.x * 8; c < a.E; c += blockDim.x * 8) *(u32x4*)(out + c) = *(const u32x4*)(row + c);
+  OT* out = (OT*)a.out + ((int64_t)bx * a.S + s) * a.ldo;
+  const OT* row = (const OT*)a.table + id * a.E;
+  constexpr int V = 16 / (int)sizeof(OT);
+  for (int c = threadIdx.x * V; c < a.E; c += blockDim.x * V) *(u32x4*)(out + c) = *(const u32x4*)(row + c);
+  auto cvt = [](float v) -> OT { if constexpr (sizeof(OT) == 2) return f2bf(v); else return v; };
   for (int c = threadIdx.x; c < a.F; c += blockDim.x) {
     const int64_t src = ((int64_t)b * a.F + c) * a.S + s;
-    out[a.E + c] = f2bf(a.y[src]);
-    out[a.E + a.F + c] = f2bf((uncond || !a.use_cond) ? 0.f : a.cond[src]);
+    out[a.E + c] = cvt(a.y[src]);
+    out[a.E + a.F + c] = cvt((uncond || !a.use_cond) ? 0.f : a.cond[src]);
   }
-  for (int c = a.E + 2 * a.F + threadIdx.x; c < a.ldo; c += blockDim.x) out[c] = 0;
+  for (int c = a.E + 2 * a.F + threadIdx.x; c < a.ldo; c += blockDim.x) out[c] = cvt(0.f);
+}
+
+// Attention probabilities of the exact-f32 Voicebox plan, in place: x[row][h*ldseg + j] holds (q_i . k_j) already scaled;
+// p = softmax_j(x + bias) with bias = -slope_h |i - j| (0 for key 0: networks.py:319-327) over keys j < kv_len[b], masked keys
+// get probability 0 exactly as finfo.min does in the reference (networks.py:334-341), pad columns [n, npad) are zeroed.
+// One wave per (row, head); same operation order as torch (add bias, subtract the row maximum, exp, sum, divide).
+__global__ __launch_bounds__(256) void softmax_alibi_kernel(float* x, int rows, int rows_per_batch, int nseg, int n, int npad, int64_t ldrow,
+                                                            int ldseg, const float* slopes, const int* kv_len, int col0_zero) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= rows * nseg) return;
+  const int row = id / nseg, h = id - row * nseg;
+  const int b = row / rows_per_batch, i = row - b * rows_per_batch;
+  const int len = kv_len ? min(kv_len[b], n) : n;
+  const float slope = slopes ? slopes[h] : 0.f;
+  float* p = x + (int64_t)row * ldrow + (int64_t)h * ldseg;
+  float m = -INFINITY;
+  for (int j = lane; j < len; j += 64) {
+    const float bias = (col0_zero && j == 0) ? 0.f : -slope * fabsf((float)(i - j));
+    const float v = p[j] + bias;
+    p[j] = v;
+    m = fmaxf(m, v);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int j = lane; j < len; j += 64) { const float e = expf(p[j] - m); p[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < npad; j += 64) p[j] = j < len ? p[j] * inv : 0.f;
 }
 
 // sinusoidal time token into row 0 of every batch (networks.py:19-28, 312-313)
@@ -74,7 +106,18 @@ extern "C" int usdm_vb_build_input(const usdm_vb_input_args* pa, usdm_stream_t s
   USDM_CHECK_ARG(a.B_in > 0 && (a.dup == 1 || a.dup == 2) && a.S > 0 && a.E % 8 == 0 && a.ldo >= a.E + 2 * a.F && a.ldo % 8 == 0,
                  "usdm_vb_build_input: bad sizes");
   USDM_CHECK_ARG(!a.use_cond || a.cond, "usdm_vb_build_input: cond missing");
-  hipLaunchKernelGGL(vb_build_input_kernel, dim3(a.S, a.B_in * a.dup), dim3(256), 0, (hipStream_t)stream, a);
+  USDM_CHECK_ARG(a.out_dtype == USDM_BF16 || a.out_dtype == USDM_F32, "usdm_vb_build_input: out_dtype");
+  if (a.out_dtype == USDM_F32) hipLaunchKernelGGL(vb_build_input_kernel<float>, dim3(a.S, a.B_in * a.dup), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(vb_build_input_kernel<bf16_t>, dim3(a.S, a.B_in * a.dup), dim3(256), 0, (hipStream_t)stream, a);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int usdm_softmax_alibi(float* x, int32_t rows, int32_t rows_per_batch, int32_t nheads, int32_t n, int32_t npad, int64_t ldrow,
+                                  int32_t ldseg, const float* slopes, const int32_t* kv_len, int32_t col0_zero, usdm_stream_t stream) {
+  USDM_CHECK_ARG(x && rows > 0 && rows_per_batch > 0 && nheads > 0 && n > 0 && npad >= n && ldseg >= npad, "usdm_softmax_alibi: bad args");
+  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv((int64_t)rows * nheads, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, rows_per_batch,
+                     nheads, n, npad, ldrow, ldseg, slopes, kv_len, col0_zero);
   USDM_LAUNCH_CHECK();
   return 0;
 }

@@ -169,8 +169,15 @@ def vb_build_input(ids, y, cond, table, out, *, B_in, dup, S, E, F, null_id, use
     a = VbInputArgs()
     a.ids, a.y, a.cond, a.table = _ptr(ids), _ptr(y), _ptr(cond), _ptr(table)
     a.B_in, a.dup, a.S, a.E, a.F, a.null_id, a.use_cond = B_in, dup, S, E, F, null_id, int(use_cond)
-    a.out, a.ldo = _ptr(out), ldo
+    a.out, a.ldo, a.out_dtype = _ptr(out), ldo, _dt(out)
+    assert table.dtype == out.dtype
     _go(plan, "usdm_vb_build_input", lib.usdm_vb_build_input, C_.byref(a))
+
+
+def softmax_alibi(x, *, rows, rows_per_batch, nheads, n, npad, ldrow, ldseg, slopes=None, kv_len=None, col0_zero=True, plan=None):
+    _need_cuda(x, slopes, kv_len)
+    _go(plan, "usdm_softmax_alibi", lib.usdm_softmax_alibi, _ptr(x), C_.c_int32(rows), C_.c_int32(rows_per_batch), C_.c_int32(nheads),
+        C_.c_int32(n), C_.c_int32(npad), C_.c_int64(ldrow), C_.c_int32(ldseg), _ptr(slopes), _ptr(kv_len), C_.c_int32(int(col0_zero)))
 
 
 def vb_time_token(t, freqs, h32, h16, *, Bx, H, rows_per_batch, t_stride=1, plan=None):

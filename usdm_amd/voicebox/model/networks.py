@@ -112,6 +112,18 @@ class Transformer(nn.Module):
         self.skip_connections_layers = nn.ModuleList([nn.Linear(2 * hidden_size, hidden_size) for _ in range(num_hidden_layers // 2)])
         self.proj_out = nn.Conv1d(hidden_size, n_feats, kernel_size=1)
         self._packed, self._plans = None, LRU(MAX_PLANS)
+        # torch.bfloat16 (default): bf16 MFMA operands, f32 accumulation / residual stream / LayerNorm / softmax statistics.
+        # torch.float32: every GEMM on the exact-f32 matrix cores and f32 attention probabilities - the reference's own precision
+        # (networks.py runs fp32 end to end), ~10x slower; the measured other side of the bf16 trade.
+        self.compute_dtype = torch.bfloat16
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self.invalidate()
+        return self
 
     def invalidate(self):
         self._packed, self._plans = None, LRU(MAX_PLANS)
@@ -128,7 +140,7 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------ packing (load-time plumbing)
     def _pack(self, dev):
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.compute_dtype, torch.float32     # `bf` = the GEMM operand dtype of the plan (bf16 by default)
         H, E, F_ = self.hidden_size, self.embedding_dim, self.n_feats
         g = lambda t: t.detach().to(dev, f32)
         P = {}
@@ -171,6 +183,8 @@ class Transformer(nn.Module):
         """Pre-built launch sequence for one estimator evaluation at batch B_in*dup, S1 frames."""
         if self._packed is None:
             self._packed = self._pack(dev)
+        if self.compute_dtype == torch.float32:
+            return self._build_plan_f32(B_in, S1, dup, use_cond, dev, ragged)
         P = self._packed
         bf, f32 = torch.bfloat16, torch.float32
         H, I, F_, E, nh, L = self.hidden_size, self.intermediate_size, self.n_feats, self.embedding_dim, self.num_heads, self.num_hidden_layers
@@ -270,6 +284,100 @@ class Transformer(nn.Module):
             ops.mask_time(vl, B=Bx, T=S1, C=F_, layout=1, off=1, x32=io["out"], plan=plan)
         return plan, io
 
+    def _build_plan_f32(self, B_in, S1, dup, use_cond, dev, ragged=False):
+        """The same estimator evaluation with every product on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32: an f32 fma
+        chain, bit for bit) and the attention probabilities materialised in f32 (two grouped GEMMs around usdm_softmax_alibi, as
+        the XLS-R encoder does): the precision the reference itself runs at (networks.py:302-374).  One f32 buffer serves as
+        GEMM operand AND residual, so the bf16 operand copies of the default plan disappear."""
+        P = self._packed
+        f32 = torch.float32
+        H, I, F_, E, nh, L = self.hidden_size, self.intermediate_size, self.n_feats, self.embedding_dim, self.num_heads, self.num_hidden_layers
+        hd = H // nh
+        Bx, S = B_in * dup, S1 + 1
+        Sp = (S + 15) // 16 * 16
+        R = Bx * S
+        plan = ops.Plan()
+        Z = lambda *s, dt=f32: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
+        io = dict(ids=Z(B_in, S1, dt=torch.int64), y=Z(B_in, F_, S1), cond=Z(B_in, F_, S1), t=Z(Bx), out=Z(Bx, F_, S1),
+                  kv_len=plan.hold(torch.full((Bx,), S, dtype=torch.int32, device=dev)))
+        ain = Z(Bx * S1, P["kinp"])
+        arena = Z(L // 2 + 2, R, H)          # slot 0: current h, slot 1: skip-linear output, 2..: skip stack
+        tmp, mid, pc = Z(R, H), Z(R, H), Z(R, H)
+        qk, vt = Z(R, 2 * H), Z(H, Bx * Sp)
+        sc = Z(Bx, S, nh * Sp)
+        ao, ff = Z(R, H), Z(R, I)
+        vl = io["kv_len"]
+        mk = dict(valid_len=vl, rows_per_batch=S) if ragged else {}
+
+        ops.vb_build_input(io["ids"], io["y"], io["cond"], P["table"], ain, B_in=B_in, dup=dup, S=S1, E=E, F=F_,
+                           null_id=self.n_tok - 1, use_cond=use_cond, ldo=P["kinp"], plan=plan)
+        cur = arena[0]
+        ops.vb_time_token(io["t"], P["freqs"], cur, None, Bx=Bx, H=H, rows_per_batch=S, plan=plan)
+        ops.gemm(ain, P["w_in"], M=S1, N=H, Kc=P["kinp"], lda=P["kinp"], rowsA=S1, batch=Bx, a_bstride=S1 * P["kinp"],
+                 c_bstride=S, c_row_off=1, bias=P["b_in"], out32=cur, ldc=H, plan=plan)
+        if ragged:
+            ops.mask_time(vl, B=Bx, T=S, C=H, layout=0, x32=cur, plan=plan)
+        G, kw = self.convpos_groups, self.convpos_width
+        cg = H // G
+        src = cur
+        for i, (w, b) in enumerate(P["pos"]):
+            dst = tmp if i == len(P["pos"]) - 1 else pc
+            ops.gemm(src, w, M=S, N=cg, Kc=cg, taps=kw, lda=H, rowsA=S, a_row_off=-(kw // 2), a_row_step=1, groups=G, batch=Bx,
+                     a_gstride=cg, w_gstride=cg * kw * cg, a_bstride=S * H, c_gcol=cg, c_bstride=S, bias=b, act=ACT_GELU,
+                     out32=dst, ldc=H, plan=plan)
+            if ragged and dst is pc:
+                ops.mask_time(vl, B=Bx, T=S, C=H, layout=0, x32=pc, plan=plan)
+            src = dst
+        slot = 2
+        ops.norm(tmp, *P["ln0"], rows=R, C=H, res=cur, out32=arena[slot], plan=plan, **mk)
+        cur = arena[slot]
+        stack = [slot]
+        slot += 1
+
+        def layer(lp, x, out):
+            """x: f32 [R][H] (operand and residual); out: where the layer's output goes"""
+            ops.gemm(x, lp["wqkv"], M=R, N=2 * H, Kc=H, bias=lp["bqkv"], out32=qk, plan=plan)                      # q (pre-scaled), k
+            ops.gemm(x, lp["wqkv"][2 * H:], M=S, N=H, Kc=H, bias=lp["bqkv"][2 * H:], rowsA=S, batch=Bx, a_bstride=S * H,
+                     c_bstride=Sp, out32=vt, ldc=Bx * Sp, transpose_out=True, plan=plan)                          # V^T [H][Bx][Sp]
+            for b in range(Bx):
+                qb = qk[b * S:(b + 1) * S]
+                ops.gemm(qb, qb[:, H:], M=S, N=S, Kc=hd, lda=2 * H, ldw=2 * H, rowsA=S, groups=nh, a_gstride=hd, w_gstride=hd,
+                         c_gcol=Sp, out32=sc[b], ldc=nh * Sp, plan=plan)
+            ops.softmax_alibi(sc, rows=R, rows_per_batch=S, nheads=nh, n=S, npad=Sp, ldrow=nh * Sp, ldseg=Sp, slopes=P["slopes"],
+                              kv_len=vl, col0_zero=True, plan=plan)
+            for b in range(Bx):
+                ops.gemm(sc[b], vt[:, b * Sp:], M=S, N=hd, Kc=Sp, lda=nh * Sp, ldw=Bx * Sp, rowsA=S, groups=nh, a_gstride=Sp,
+                         w_gstride=hd * Bx * Sp, c_gcol=hd, out32=ao[b * S:(b + 1) * S], ldc=H, plan=plan)
+            ops.gemm(ao, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=x, ldr=H, out32=tmp, plan=plan)
+            ops.norm(tmp, *lp["ln1"], rows=R, C=H, out32=mid, plan=plan, **mk)
+            ops.gemm(mid, lp["w1"], M=R, N=I, Kc=H, bias=lp["b1"], act=ACT_GELU, out32=ff, plan=plan)
+            ops.gemm(ff, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=mid, ldr=H, out32=tmp, plan=plan)
+            ops.norm(tmp, *lp["ln2"], rows=R, C=H, out32=out, plan=plan, **mk)
+
+        for n in range(L):
+            lp = P["layers"][n]
+            if n < L // 2:
+                push = n < L // 2 - 1
+                dst = arena[slot] if push else arena[0]
+                layer(lp, cur, dst)
+                cur = dst
+                if push:
+                    stack.append(slot)
+                    slot += 1
+            else:
+                sk = stack.pop()
+                w, b = P["skips"][n - L // 2]
+                assert cur.data_ptr() == arena[0].data_ptr()
+                ops.gemm(arena, w, M=R, N=H, Kc=H, taps=2, lda=H, rowsA=R, a_tap_stride=sk * R * H, bias=b, out32=arena[1], plan=plan)
+                layer(lp, arena[1], arena[0])
+                cur = arena[0]
+        assert not stack
+        ops.gemm(cur[1:], P["w_out"], M=S1, N=F_, Kc=H, lda=H, rowsA=S1, batch=Bx, a_bstride=S * H, c_bstride=F_ * S1,
+                 bias=P["b_out"], out32=io["out"], ldc=S1, transpose_out=True, plan=plan)
+        if ragged:
+            ops.mask_time(vl, B=Bx, T=S1, C=F_, layout=1, off=1, x32=io["out"], plan=plan)
+        return plan, io
+
     @staticmethod
     def bucket_frames(S1):
         """Frame count a plan is built for: the token-prefixed length S1 + 1 rounded up to FRAME_BUCKET rows.  Any utterance
@@ -278,7 +386,7 @@ class Transformer(nn.Module):
         return bucket(S1 + 1, FRAME_BUCKET) - 1
 
     def get_plan(self, B_in, S1, dup, use_cond, dev, ragged=False):
-        key = (B_in, S1, dup, bool(use_cond), dev.index, bool(ragged))
+        key = (B_in, S1, dup, bool(use_cond), dev.index, bool(ragged), self.compute_dtype)
 
         def build():
             plan, io = self.build_plan(B_in, S1, dup, use_cond, dev, ragged)
