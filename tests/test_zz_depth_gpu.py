@@ -132,9 +132,9 @@ def test_config4_voicebox_63_nfe_bf16_and_f32_plans_vs_oracle(dev):
         rel[name] = ((outs[name] - ref).norm() / ref.norm()).item()
         # the generated part only (the prompt region is re-noised data the solver overwrites: voicebox.py:115-117)
         gen = ((outs[name][:, :, P:] - ref[:, :, P:]).norm() / ref[:, :, P:].norm()).item()
-        show = [f"{per[name][i]:.4f}" for i in (0, 1, 8, 16, 24, 32, 40, 48, 56, 62)]
-        print(f"config 4 voicebox, 63 chained NFE (Heun 64, CFG 1.0, prompt 256, S=1117), {name} plan: final mel rel L2 {rel[name]:.5f} "
-              f"(generated frames only {gen:.5f}); velocity rel L2 at NFE 1,2,9,17,25,33,41,49,57,63 {show}; max {max(per[name]):.4f}; "
+        show = [f"{per[name][i]:.2e}" for i in (0, 1, 8, 16, 24, 32, 40, 48, 56, 62)]
+        print(f"config 4 voicebox, 63 chained NFE (Heun 64, CFG 1.0, prompt 256, S=1117), {name} plan: final mel rel L2 {rel[name]:.3e} "
+              f"(generated frames only {gen:.3e}); velocity rel L2 at NFE 1,2,9,17,25,33,41,49,57,63 {show}; max {max(per[name]):.2e}; "
               f"{ms[name]:.0f} ms on the GPU")
     print(f"CPU oracle: {t_or:.0f} s for 63 NFE")
     assert rel["bf16"] <= 3e-2 and per["bf16"][0] <= 1e-2 and max(per["bf16"]) <= 3e-2      # stated tolerance, SURVEY.md 8d

@@ -1,0 +1,43 @@
+"""Voicebox attention launch time (S=1118, 2 x 16 heads, d=64), first form vs the LDS-DMA / pipelined form, hipGraph replay of
+24 launches over 24 distinct Q/K/V sets (as in the 24-layer stack)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from usdm_amd import ops
+from usdm_amd.graph import GraphedPlan
+dev = torch.device("cuda:0")
+Bx, nh, S = 2, 16, 1118
+Spad = (S + 63) // 64 * 64
+bf = torch.bfloat16
+L = 24
+qs = [torch.randn(Bx, nh, Spad, 64, device=dev).to(bf) * 0.5 for _ in range(L)]
+ks = [torch.randn(Bx, nh, Spad, 64, device=dev).to(bf) * 0.5 for _ in range(L)]
+vts = [torch.randn(Bx, nh, 64, Spad, device=dev).to(bf) for _ in range(L)]
+H = nh * 64
+slopes = torch.tensor([2 ** (-(i + 1) / 2) for i in range(nh)], device=dev)
+kvl = torch.tensor([S, S], dtype=torch.int32, device=dev)
+outs = {}
+for v2 in ("0", "1"):
+    os.environ["USDM_ATTN_V2"] = v2
+    o = torch.zeros(Bx * S, H, device=dev, dtype=bf)
+    plan = ops.Plan()
+    for i in range(L):
+        ops.attention(qs[i], ks[i], vts[i], o, mode=0, dh=64, B=Bx, Hq=nh, Hkv=nh, Sq=S, Skv=S, Skv_alloc=Spad,
+                      q_strides=(nh * Spad * 64, Spad * 64, 64), k_strides=(nh * Spad * 64, Spad * 64, 64),
+                      v_strides=(nh * 64 * Spad, 64 * Spad, Spad), o_strides=(S * H, H), scale=1.0, kv_len=kvl, slopes=slopes,
+                      alibi_col0_zero=True, plan=plan)
+    gp = GraphedPlan(plan)
+    for _ in range(3):
+        gp.run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        gp.run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (10 * L)
+    fl = 4 * Bx * nh * S * S * 64
+    print(f"USDM_ATTN_V2={v2}: {us:6.2f} us per launch  ({fl / us / 1e6:5.0f} TF/s)", flush=True)
+    outs[v2] = o.float().clone()
+d = (outs["0"] - outs["1"]).abs()
+print(f"max |v1 - v2| {d.max().item():.4f} (max |o| {outs['0'].abs().max().item():.3f}), mean {d.mean().item():.2e}")

@@ -341,6 +341,288 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
       }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Voicebox attention, second form (head dim 64, bidirectional ALiBi): the same mathematics and the same orientation
+// (S^T = K.Q^T, P^T fed back from the accumulator registers) re-cut around what the first form's counters showed
+// (profiles/r01_gemm_ablation.txt: 13.7 VALU instructions per score, VALU issue 47 %, MFMA 13 %, nothing overlapped):
+//   * K and V^T tiles travel global -> LDS by LDS-DMA (buffer_load ... lds, 8 rows x 128 B per instruction, XOR swizzle on the
+//     source side) into a 4-slot ring, three tiles ahead: no staging registers, no per-tile address arithmetic (one scalar
+//     offset per tile), one barrier per tile;
+//   * the key rows of a 32-key sub-tile are PERMUTED on their way into the S^T MFMA (lane r multiplies key kappa(r), kappa = r
+//     with bits 2 and 3 swapped): accumulator registers 8s..8s+7 of lane half h then hold the 8 CONSECUTIVE keys
+//     16s + 8h .. +7, so the V^T operand of O^T += V^T.P^T is ONE ds_read_b128 of 8 consecutive keys - K and V^T share one LDS
+//     image and one conflict-free read pattern (the first form needed two ds_read_b64 per fragment and an image LDS-DMA cannot fill);
+//   * software pipeline inside the wave (one wave per SIMD, 512 registers): S^T of tile t+1 is on the matrix pipe while the
+//     VALU exponentiates tile t, and O^T += V^T.P^T of tile t runs under the bias / maximum pass of tile t+1;
+//   * the ALiBi term of a tile that lies wholly on one side of the wave's queries is split into a per-register constant
+//     (folded into the scaling FMA) and a per-lane, per-tile scalar that only shifts the running maximum: 1 FMA per score.
+// Results differ from the first form only by the order of f32 additions in the row sums.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int kappa32(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
+  constexpr int DH = 64, NSL = 4, TILE = KT * 128;              // one operand tile: 64 rows x 128 B
+  constexpr int SLOT = 2 * TILE;                                 // K tile + V^T tile
+  __shared__ __attribute__((aligned(16))) char smem[NSL * SLOT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, lh = lane >> 5;
+  const int qb = blockIdx.x;
+  const int lin = blockIdx.y + gridDim.y * blockIdx.z;
+  const int h = (int)gridDim.y - 1 - lin / (int)gridDim.z;       // flattest slope first (see attn_kernel)
+  const int b = lin % (int)gridDim.z;
+  const int hk = h / (a.Hq / a.Hkv);
+  const int q0 = qb * 128 + wv * 32;
+  const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
+  const int ntiles = (kv_len + KT - 1) / KT;
+
+  const bf16_t* Q = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
+  const bf16_t* K = (const bf16_t*)a.k + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs;
+  const bf16_t* V = (const bf16_t*)a.vt + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs;
+  auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, 0x80000000u, 0x00020000);
+  auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x80000000u, 0x00020000);
+
+  // ---- LDS-DMA: wave w moves row blocks 2w, 2w+1 (8 rows each) of the K tile and of the V^T tile.  LDS slot c' of row r
+  // receives logical 16-B piece c' ^ swz(r), swz(r) = (r >> 1) & 7: conflict-free ds_read_b128 for the 32x32x16 operand rows.
+  unsigned vofK[2], vofV[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (2 * wv + i) * 8 + (lane >> 3);
+    const int pc = (lane & 7) ^ ((r >> 1) & 7);
+    vofK[i] = (unsigned)r * (unsigned)(a.k_rs * 2) + (unsigned)(pc << 4);
+    vofV[i] = (unsigned)r * (unsigned)(a.v_ds * 2) + (unsigned)(pc << 4);
+  }
+  const unsigned OOB = 0xFFFFFFF0u;
+  auto dma_tile = [&](int kt) {          // always 4 instructions per wave (a tile past the end fetches nothing: counted waits stay exact)
+    char* sl = smem + (kt & (NSL - 1)) * SLOT;
+    const bool ok = kt < ntiles;
+    const unsigned soK = (unsigned)kt * (unsigned)(KT * a.k_rs * 2), soV = (unsigned)kt * (unsigned)(KT * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(sl + (2 * wv + i) * 1024), 16,
+                                               ok ? vofK[i] : OOB, ok ? soK : 0u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(sl + TILE + (2 * wv + i) * 1024), 16,
+                                               ok ? vofV[i] : OOB, ok ? soV : 0u, 0, 0);
+    }
+  };
+  dma_tile(0); dma_tile(1); dma_tile(2);
+
+  // Q fragments (B operand of S^T): lane holds Q[q0+lq][16s + 8*lh .. +7]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + lq;
+    if (qr > a.Sq - 1) qr = a.Sq - 1;
+    const bf16_t* qp = Q + (int64_t)qr * a.q_rs + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + 16 * s));
+  }
+  // fragment byte offsets inside a tile image (loop invariants).  K operand of sub-tile u, d-step s: row kappa(lq) + 32u, piece
+  // 2s + lh.  V^T operand of d-tile t, key step (u, s'): row 32t + lq, piece 4u + 2s' + lh.
+  unsigned foK[2][4], foV[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rk = 32 * u + kappa32(lq), rv = 32 * u + lq;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      foK[u][s] = rk * 128 + (((2 * s + lh) ^ ((rk >> 1) & 7)) << 4);
+      foV[u][s] = TILE + rv * 128 + (((2 * s + lh) ^ ((rv >> 1) & 7)) << 4);     // [d-tile u][key piece pair s]: pieces 2s + lh
+    }
+  }
+  const int qpos = a.q_pos0 + q0 + lq;
+  const float slope = a.slopes ? a.slopes[h] : 0.f;
+  const float sc = a.scale * 1.4426950408889634f, slope2 = slope * 1.4426950408889634f;
+  // key of accumulator register i of sub-tile u in lane half lh: 32u + 16(i >> 3) + 8 lh + (i & 7); cbc = slope2 * (its offset from
+  // the lane's base key kt*64 + 8 lh)
+  float cbc[2][16];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cbc[u][i] = slope2 * (float)(32 * u + 16 * (i >> 3) + (i & 7));
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int qw0 = a.q_pos0 + q0;
+
+  // S^T of tile kt from its LDS slot
+  auto qk = [&](f32x16 (&sa)[2], int kt) {
+    const char* sl = smem + (kt & (NSL - 1)) * SLOT;
+    u32x4 kf[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[u][s] = *(const u32x4*)(sl + foK[u][s]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[u][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        sa[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[u][s]), qf[s], sa[u], 0, 0, 0);
+    }
+  };
+  // scale + bias + mask + running maximum of tile kt: sa <- s' (true score minus the lane's tile shift `ash`); returns whether the
+  // tile can be skipped.  On return m_run is the new maximum, alpha the factor the old state must be scaled by, msub = m_run - ash.
+  auto part1 = [&](f32x16 (&sa)[2], int kt, float& alpha, float& msub) -> bool {
+    const int kbase = kt * KT + 8 * lh;
+    const float fq = (float)(qpos - kbase);
+    const bool k_left = kt * KT + KT - 1 <= qw0, k_right = kt * KT >= qw0 + 31;
+    float ash = 0.f;
+    if (k_left || k_right) {
+      ash = k_left ? -slope2 * fq : slope2 * fq;
+      if (kt == 0 && a.alibi_col0_zero && lh == 0) {            // key 0 carries no ALiBi bias (networks.py:327): true = s*sc
+        const float s00 = fmaf(sa[0][0], sc, -ash);
+        if (k_left) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, cbc[u][i]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, -cbc[u][i]);
+        }
+        sa[0][0] = s00;
+      } else if (k_left) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, cbc[u][i]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, -cbc[u][i]);
+      }
+    } else {                                                      // the (at most two) tiles that straddle the wave's queries
+      const float s00 = sa[0][0] * sc;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float c = (float)(32 * u + 16 * (i >> 3) + (i & 7));
+          sa[u][i] = fmaf(sa[u][i], sc, -slope2 * fabsf(fq - c));
+        }
+      if (kt == 0 && a.alibi_col0_zero && lh == 0) sa[0][0] = s00;
+    }
+    if (kt * KT + KT > kv_len) {                                  // keys past the sequence end (bucket padding): masked
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kpos = kbase + 32 * u + 16 * (i >> 3) + (i & 7);
+          sa[u][i] = kpos < kv_len ? sa[u][i] : -1e30f;
+        }
+    }
+    float mloc = -1e30f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sa[u][i]);
+    mloc += ash;                                                  // back to the true score domain (masked: stays ~ -1e30)
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const bool skip = __all(mloc < m_run - 40.0f);                // < 2^-34 of a denominator >= 1: invisible in f32 (see attn_kernel)
+    if (skip) { alpha = 1.0f; msub = 0.f; return true; }
+    const float m_new = fmaxf(m_run, mloc);
+    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    msub = m_new - ash;
+    return false;
+  };
+  // exponentials of tile kt (sa holds s'), row sums, rescale of the running state, P^T as bf16 MFMA operands
+  auto part2 = [&](f32x16 (&sa)[2], float alpha, float msub, bf16x8 (&pf)[2][2]) {
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sa[u][i] - msub);  // masked scores (-1e30) underflow to exactly 0
+        sa[u][i] = p;
+        ps += p;
+      }
+    l_run = l_run * alpha + ps;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[u][s][j] = (__bf16)sa[u][8 * s + j];
+  };
+  // O^T += V^T . P^T of tile kt
+  auto pv = [&](const bf16x8 (&pf)[2][2], int kt) {
+    const char* sl = smem + (kt & (NSL - 1)) * SLOT;
+    u32x4 vf[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vf[t][g] = *(const u32x4*)(sl + foV[t][g]);      // g = 2u + s': keys 32u + 16s' + 8 lh .. +7
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[t][2 * u + s]), pf[u][s], oacc[t], 0, 0, 0);
+  };
+
+  f32x16 sA[2], sB[2];
+  bf16x8 pf[2][2];
+  float alpha = 1.f, msub = 0.f;
+  bool skip = true;
+  // prologue: tile 0 landed (tiles 1, 2 may still be in flight: 8 instructions)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (ntiles > 0) { qk(sA, 0); skip = part1(sA, 0, alpha, msub); }
+  // one pipelined step: tile t is in `cur` (scores s'), tile t+1 goes into `nxt`
+  auto step = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], int t) {
+    // tile t+1 has landed in every wave's view after this wait + barrier (tile t+2 may be in flight); tile t-1's slot is free
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    dma_tile(t + 3);
+    const bool more = t + 1 < ntiles;
+    if (more) qk(nxt, t + 1);
+    const float al = alpha, ms = msub;
+    const bool sk = skip;
+    if (!sk) part2(cur, al, ms, pf);
+    if (!sk) pv(pf, t);
+    if (more) skip = part1(nxt, t + 1, alpha, msub);
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(sA, sB, t);
+    if (t + 1 < ntiles) step(sB, sA, t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the trailing no-op DMA instructions)
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int qr = q0 + lq;
+  if (qr < a.Sq) {
+    bf16_t* op = (bf16_t*)a.o + (int64_t)b * a.o_bs + (int64_t)qr * a.o_rs + h * DH;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * lh;
+        uint2 o;
+        o.x = pack_bf2(oacc[t][4 * g + 0] * inv, oacc[t][4 * g + 1] * inv);
+        o.y = pack_bf2(oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+        *(uint2*)(op + d) = o;
+      }
+  }
+}
 }  // namespace
 
 #ifdef USDM_ATTN_TRACE
@@ -375,6 +657,14 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
     if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a);        \
     else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a);              \
   } while (0)
+  // Voicebox shape: the LDS-DMA / software-pipelined form (USDM_ATTN_V2=0 restores the first form for A/B runs)
+  const int v2 = getenv("USDM_ATTN_V2") ? atoi(getenv("USDM_ATTN_V2")) : 1;   // (read per call: tests compare the two forms in one process)
+  if (a.dh == 64 && a.mode == 0 && v2 && !small && a.Hq % a.Hkv == 0 && (a.k_rs * 2) % 16 == 0 && (a.v_ds * 2) % 16 == 0 &&
+      (int64_t)cdiv(a.Skv, KT) * KT * a.k_rs * 2 < 0x7FFFFF00ll && (int64_t)64 * a.v_ds * 2 < 0x7FFFFF00ll) {
+    hipLaunchKernelGGL(attn_vb_kernel, dim3(cdiv(a.Sq, 128), a.Hq, a.B), dim3(256), 0, st, a);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.dh == 64 && a.mode == 0) USDM_ATTN(64, 0);
   else if (a.dh == 64) USDM_ATTN(64, 1);
   else if (a.mode == 0) USDM_ATTN(128, 0);

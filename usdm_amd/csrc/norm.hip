@@ -131,6 +131,7 @@ extern "C" int usdm_norm(const usdm_norm_args* pa, usdm_stream_t stream) {
   dim3 grid(cdiv(a.rows, 4)), block(256);
   const int np = cdiv(a.C, 256);
   if (np <= 2) hipLaunchKernelGGL(norm_kernel<2>, grid, block, 0, st, a);
+  else if (np == 4) hipLaunchKernelGGL(norm_kernel<4>, grid, block, 0, st, a);   // C = 1024 (Voicebox): no idle fifth piece
   else if (np <= 5) hipLaunchKernelGGL(norm_kernel<5>, grid, block, 0, st, a);
   else if (np <= 16) hipLaunchKernelGGL(norm_kernel<16>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(norm_kernel<MAXP>, grid, block, 0, st, a);

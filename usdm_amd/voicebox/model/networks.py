@@ -235,7 +235,11 @@ class Transformer(nn.Module):
         import os
         use_split = os.environ.get("USDM_VB_SPLITK", "1") == "1" and I >= 4 * H and R >= 1024
         nsp = int(os.environ.get("USDM_VB_SPLITK_N", "3"))
-        split2 = plan.hold(torch.zeros(nsp, R, H, device=dev, dtype=torch.float32)) if use_split else None
+        # out-proj (2236 x 1024 x 1024: 144 tiles of 128x128 leave 44 % of the CUs idle): optional split-K whose partials the
+        # LayerNorm behind it sums exactly as for FFN2 (USDM_VB_WO_SPLIT = number of splits, 0 = off)
+        wo_split = int(os.environ.get("USDM_VB_WO_SPLIT", "0")) if R >= 1024 else 0
+        nbuf = max(nsp if use_split else 0, wo_split)
+        split2 = plan.hold(torch.zeros(nbuf, R, H, device=dev, dtype=torch.float32)) if nbuf else None
 
         def layer(lp, cur, out16):
             ops.gemm(cur, lp["wqkv"], M=R, N=3 * H, Kc=H, bias=lp["bqkv"], plan=plan,
@@ -244,10 +248,16 @@ class Transformer(nn.Module):
                           q_strides=(nh * Spad * 64, Spad * 64, 64), k_strides=(nh * Spad * 64, Spad * 64, 64),
                           v_strides=(nh * 64 * Spad, 64 * Spad, Spad), o_strides=(S * H, H), scale=1.0,
                           kv_len=io["kv_len"], slopes=slopes, alibi_col0_zero=True, plan=plan)
-            ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=tmp32, plan=plan)
-            ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan, **mk)
+            if wo_split > 1:
+                ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=split2, split_k=wo_split,
+                         c_split_stride=R * H, plan=plan)
+                ops.norm(split2[0], *lp["ln1"], rows=R, C=H, res=split2[1], out32=h32, out16=pc16, plan=plan,
+                         **(dict(res2=split2[2], n_res2=wo_split - 2, res2_stride=R * H) if wo_split > 2 else {}), **mk)
+            else:
+                ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=tmp32, plan=plan)
+                ops.norm(tmp32, *lp["ln1"], rows=R, C=H, out32=h32, out16=pc16, plan=plan, **mk)
             ops.gemm(pc16, lp["w1"], M=R, N=I, Kc=H, bias=lp["b1"], act=ACT_GELU, out16=f16, plan=plan)
-            if split2 is not None:
+            if use_split:
                 # deep-K GEMM with only 9 x 8 output tiles of 256x128: three split-K partials (one round of 216 workgroups);
                 # the LayerNorm that follows sums them (its residual inputs), in split order
                 ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=h32, ldr=H, out32=split2, split_k=nsp,
