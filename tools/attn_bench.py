@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from usdm_amd import ops
 from usdm_amd.graph import GraphedPlan
 dev = torch.device("cuda:0")
-Bx, nh, S = 2, 16, 1118
+Bx, nh, S = int(os.environ.get("AB_B", "2")), int(os.environ.get("AB_H", "16")), int(os.environ.get("AB_S", "1118"))
 Spad = (S + 63) // 64 * 64
 bf = torch.bfloat16
 L = 24
@@ -16,7 +16,7 @@ ks = [torch.randn(Bx, nh, Spad, 64, device=dev).to(bf) * 0.5 for _ in range(L)]
 vts = [torch.randn(Bx, nh, 64, Spad, device=dev).to(bf) for _ in range(L)]
 H = nh * 64
 slopes = torch.tensor([2 ** (-(i + 1) / 2) for i in range(nh)], device=dev)
-kvl = torch.tensor([S, S], dtype=torch.int32, device=dev)
+kvl = torch.tensor([S] * Bx, dtype=torch.int32, device=dev)
 outs = {}
 for v2 in ("0", "1"):
     os.environ["USDM_ATTN_V2"] = v2

@@ -11,6 +11,7 @@
 // V is therefore consumed as V^T [d][key], which the producing GEMM epilogue writes directly.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/usdm_hip.h"
 
 namespace {
@@ -348,22 +349,29 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
 // (profiles/r01_gemm_ablation.txt: 13.7 VALU instructions per score, VALU issue 47 %, MFMA 13 %, nothing overlapped):
 //   * K and V^T tiles travel global -> LDS by LDS-DMA (buffer_load ... lds, 8 rows x 128 B per instruction, XOR swizzle on the
 //     source side) into a 4-slot ring, three tiles ahead: no staging registers, no per-tile address arithmetic (one scalar
-//     offset per tile), one barrier per tile;
+//     offset per tile), one barrier per 64-key tile;
 //   * the key rows of a 32-key sub-tile are PERMUTED on their way into the S^T MFMA (lane r multiplies key kappa(r), kappa = r
 //     with bits 2 and 3 swapped): accumulator registers 8s..8s+7 of lane half h then hold the 8 CONSECUTIVE keys
 //     16s + 8h .. +7, so the V^T operand of O^T += V^T.P^T is ONE ds_read_b128 of 8 consecutive keys - K and V^T share one LDS
 //     image and one conflict-free read pattern (the first form needed two ds_read_b64 per fragment and an image LDS-DMA cannot fill);
-//   * software pipeline inside the wave (one wave per SIMD, 512 registers): S^T of tile t+1 is on the matrix pipe while the
-//     VALU exponentiates tile t, and O^T += V^T.P^T of tile t runs under the bias / maximum pass of tile t+1;
-//   * the ALiBi term of a tile that lies wholly on one side of the wave's queries is split into a per-register constant
-//     (folded into the scaling FMA) and a per-lane, per-tile scalar that only shifts the running maximum: 1 FMA per score.
-// Results differ from the first form only by the order of f32 additions in the row sums.
+//   * software pipeline inside the wave (one wave per SIMD) in steps of ONE 32-key sub-tile, so that the live state (two score
+//     tiles, O^T, fragments, constants) stays well inside the register file: S^T of sub-tile j+1 is on the matrix pipe while the
+//     VALU exponentiates sub-tile j, and O^T += V^T.P^T of sub-tile j runs under the bias / maximum pass of sub-tile j+1.  The
+//     steady-state step is ONE basic block (no branch between its MFMAs and its VALU work), which is what lets the compiler's
+//     scheduler interleave the two pipes;
+//   * the ALiBi term of a sub-tile that lies wholly on one side of the wave's queries is split into a per-register constant
+//     (folded into the scaling FMA) and a per-lane, per-step scalar that only shifts the running maximum: 1 FMA per score;
+//   * the running maximum is only raised when it grows by more than 2^4 (deferred rescale): the O^T rescale becomes a rare,
+//     wave-uniform branch at the top of a step instead of 32 multiplies in every step.  P <= 2^4 keeps the same relative
+//     precision in bf16, sums stay far inside f32 range.
+// Results differ from the first form by f32 summation order and by the (exact in the limit) deferred maximum.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int kappa32(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 __global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
   constexpr int DH = 64, NSL = 4, TILE = KT * 128;              // one operand tile: 64 rows x 128 B
   constexpr int SLOT = 2 * TILE;                                 // K tile + V^T tile
+  constexpr float DEFER = 4.0f;                                  // log2 domain
   __shared__ __attribute__((aligned(16))) char smem[NSL * SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
   const int q0 = qb * 128 + wv * 32;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
   const int ntiles = (kv_len + KT - 1) / KT;
+  const int nsub = (kv_len + 31) / 32;                           // 32-key sub-tiles that hold at least one valid key
 
   const bf16_t* Q = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
   const bf16_t* K = (const bf16_t*)a.k + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs;
@@ -417,28 +426,29 @@ __global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + 16 * s));
   }
-  // fragment byte offsets inside a tile image (loop invariants).  K operand of sub-tile u, d-step s: row kappa(lq) + 32u, piece
-  // 2s + lh.  V^T operand of d-tile t, key step (u, s'): row 32t + lq, piece 4u + 2s' + lh.
-  unsigned foK[2][4], foV[2][4];
+  // fragment byte offsets inside a 64-key tile image.  K operand of sub-tile u, d-step s: row 32u + kappa(lq), piece 2s + lh
+  // (row + 32 keeps the swizzle: + 4096 bytes).  V^T operand of d-tile t, key step s' of sub-tile u: row 32t + lq, piece
+  // 4u + 2s' + lh = (2s' + lh) ^ swz with bit 2 flipped by u: ^ 64 bytes.
+  unsigned foK[4], foV[2][2];
+  {
+    const int rk = kappa32(lq);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int rk = 32 * u + kappa32(lq), rv = 32 * u + lq;
+    for (int s = 0; s < 4; ++s) foK[s] = rk * 128 + (((2 * s + lh) ^ ((rk >> 1) & 7)) << 4);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      foK[u][s] = rk * 128 + (((2 * s + lh) ^ ((rk >> 1) & 7)) << 4);
-      foV[u][s] = TILE + rv * 128 + (((2 * s + lh) ^ ((rv >> 1) & 7)) << 4);     // [d-tile u][key piece pair s]: pieces 2s + lh
+    for (int t = 0; t < 2; ++t) {
+      const int rv = 32 * t + lq;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) foV[t][s] = TILE + rv * 128 + (((2 * s + lh) ^ ((rv >> 1) & 7)) << 4);
     }
   }
   const int qpos = a.q_pos0 + q0 + lq;
   const float slope = a.slopes ? a.slopes[h] : 0.f;
   const float sc = a.scale * 1.4426950408889634f, slope2 = slope * 1.4426950408889634f;
-  // key of accumulator register i of sub-tile u in lane half lh: 32u + 16(i >> 3) + 8 lh + (i & 7); cbc = slope2 * (its offset from
-  // the lane's base key kt*64 + 8 lh)
-  float cbc[2][16];
+  // key of accumulator register i of sub-tile j in lane half lh: 32j + 8 lh + c(i), c(i) = 16(i >> 3) + (i & 7)
+  float cs[16];                                                      // sign * slope2 * c(i): the folded ALiBi constants
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) cbc[u][i] = slope2 * (float)(32 * u + 16 * (i >> 3) + (i & 7));
+  for (int i = 0; i < 16; ++i) cs[i] = slope2 * (float)(16 * (i >> 3) + (i & 7));
+  float cs_sign = 1.0f;                                              // +1: sub-tiles to the left of the queries, -1: to the right
 
   f32x16 oacc[2];
 #pragma unroll
@@ -448,163 +458,183 @@ __global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
   float m_run = -1e30f, l_run = 0.f;
   const int qw0 = a.q_pos0 + q0;
 
-  // S^T of tile kt from its LDS slot
-  auto qk = [&](f32x16 (&sa)[2], int kt) {
-    const char* sl = smem + (kt & (NSL - 1)) * SLOT;
-    u32x4 kf[2][4];
+  // ---- building blocks (j = index of a 32-key sub-tile; its tile is j >> 1, its half u = j & 1)
+  auto qk = [&](f32x16& sa, int j) {                                 // S^T of sub-tile j
+    const char* sl = smem + ((j >> 1) & (NSL - 1)) * SLOT + (j & 1) * 4096;
+    u32x4 kf[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int s = 0; s < 4; ++s) kf[s] = *(const u32x4*)(sl + foK[s]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[u][s] = *(const u32x4*)(sl + foK[u][s]);
+    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[u][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        sa[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[u][s]), qf[s], sa[u], 0, 0, 0);
-    }
+    for (int s = 0; s < 4; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s]), qf[s], sa, 0, 0, 0);
   };
-  // scale + bias + mask + running maximum of tile kt: sa <- s' (true score minus the lane's tile shift `ash`); returns whether the
-  // tile can be skipped.  On return m_run is the new maximum, alpha the factor the old state must be scaled by, msub = m_run - ash.
-  auto part1 = [&](f32x16 (&sa)[2], int kt, float& alpha, float& msub) -> bool {
-    const int kbase = kt * KT + 8 * lh;
-    const float fq = (float)(qpos - kbase);
-    const bool k_left = kt * KT + KT - 1 <= qw0, k_right = kt * KT >= qw0 + 31;
-    float ash = 0.f;
-    if (k_left || k_right) {
-      ash = k_left ? -slope2 * fq : slope2 * fq;
-      if (kt == 0 && a.alibi_col0_zero && lh == 0) {            // key 0 carries no ALiBi bias (networks.py:327): true = s*sc
-        const float s00 = fmaf(sa[0][0], sc, -ash);
-        if (k_left) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, cbc[u][i]);
-        } else {
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, -cbc[u][i]);
-        }
-        sa[0][0] = s00;
-      } else if (k_left) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, cbc[u][i]);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sa[u][i] = fmaf(sa[u][i], sc, -cbc[u][i]);
-      }
-    } else {                                                      // the (at most two) tiles that straddle the wave's queries
-      const float s00 = sa[0][0] * sc;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float c = (float)(32 * u + 16 * (i >> 3) + (i & 7));
-          sa[u][i] = fmaf(sa[u][i], sc, -slope2 * fabsf(fq - c));
-        }
-      if (kt == 0 && a.alibi_col0_zero && lh == 0) sa[0][0] = s00;
-    }
-    if (kt * KT + KT > kv_len) {                                  // keys past the sequence end (bucket padding): masked
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int kpos = kbase + 32 * u + 16 * (i >> 3) + (i & 7);
-          sa[u][i] = kpos < kv_len ? sa[u][i] : -1e30f;
-        }
-    }
-    float mloc = -1e30f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sa[u][i]);
-    mloc += ash;                                                  // back to the true score domain (masked: stays ~ -1e30)
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const bool skip = __all(mloc < m_run - 40.0f);                // < 2^-34 of a denominator >= 1: invisible in f32 (see attn_kernel)
-    if (skip) { alpha = 1.0f; msub = 0.f; return true; }
-    const float m_new = fmaxf(m_run, mloc);
-    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    msub = m_new - ash;
-    return false;
-  };
-  // exponentials of tile kt (sa holds s'), row sums, rescale of the running state, P^T as bf16 MFMA operands
-  auto part2 = [&](f32x16 (&sa)[2], float alpha, float msub, bf16x8 (&pf)[2][2]) {
-    float ps = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(sa[u][i] - msub);  // masked scores (-1e30) underflow to exactly 0
-        sa[u][i] = p;
-        ps += p;
-      }
-    l_run = l_run * alpha + ps;
-    if (__any(alpha != 1.0f)) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[u][s][j] = (__bf16)sa[u][8 * s + j];
-  };
-  // O^T += V^T . P^T of tile kt
-  auto pv = [&](const bf16x8 (&pf)[2][2], int kt) {
-    const char* sl = smem + (kt & (NSL - 1)) * SLOT;
-    u32x4 vf[2][4];
+  auto load_v = [&](u32x4 (&vf)[2][2], int j) {
+    const char* sl = smem + ((j >> 1) & (NSL - 1)) * SLOT;
+    const unsigned x = (j & 1) ? 64u : 0u;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) vf[t][g] = *(const u32x4*)(sl + foV[t][g]);      // g = 2u + s': keys 32u + 16s' + 8 lh .. +7
+      for (int s = 0; s < 2; ++s) vf[t][s] = *(const u32x4*)(sl + (foV[t][s] ^ x));
+  };
+  // the (deferred) maximum update shared by both forms of the bias pass: mloc = this lane's best TRUE score of the sub-tile
+  float alpha = 1.f, msub = 0.f;                                     // state handed from the bias pass of sub-tile j to its exp pass
+  bool skip = true;
+  auto max_update = [&](float mloc, float ash) {
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    skip = __all(mloc < m_run - 40.0f);                              // < 2^-34 of a denominator >= 1: invisible in f32 (see attn_kernel)
+    const float m_new = (mloc > m_run + DEFER) ? mloc : m_run;       // raise the maximum only for real growth: P <= 2^DEFER
+    alpha = __builtin_amdgcn_exp2f(m_run - m_new);                   // 1 when unchanged (also for a skippable sub-tile)
+    m_run = m_new;
+    msub = m_new - ash;
+  };
+  // general bias pass: any sub-tile (straddling the queries, key 0, masked tail); sa <- s' with true score = s' + ash
+  auto part1 = [&](f32x16& sa, int j) {
+    const int kbase = 32 * j + 8 * lh;
+    const float fq = (float)(qpos - kbase);
+    const float s00 = sa[0] * sc;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int i = 0; i < 16; ++i) {
+      const float c = (float)(16 * (i >> 3) + (i & 7));
+      sa[i] = fmaf(sa[i], sc, -slope2 * fabsf(fq - c));
+    }
+    if (j == 0 && a.alibi_col0_zero && lh == 0) sa[0] = s00;         // key 0 carries no ALiBi bias (networks.py:327)
+    if (32 * j + 32 > kv_len) {                                      // keys past the sequence end (bucket padding): masked
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int i = 0; i < 16; ++i) sa[i] = (kbase + 16 * (i >> 3) + (i & 7)) < kv_len ? sa[i] : -1e30f;
+    }
+    float mloc = -1e30f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[t][2 * u + s]), pf[u][s], oacc[t], 0, 0, 0);
+    for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sa[i]);
+    max_update(mloc, 0.f);
+  };
+  // which side sub-tile j lies on for this wave: +1 left, -1 right, 0 straddling / special (key 0, masked tail)
+  auto side_of = [&](int j) -> int {
+    if (j <= 0 || 32 * j + 32 > kv_len) return 0;
+    if (32 * j + 31 <= qw0) return 1;
+    if (32 * j >= qw0 + 31) return -1;
+    return 0;
   };
 
-  f32x16 sA[2], sB[2];
-  bf16x8 pf[2][2];
-  float alpha = 1.f, msub = 0.f;
-  bool skip = true;
+  f32x16 sA, sB;
+#ifdef USDM_ATTN_TRACE
+  unsigned long long atr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tstart = ATR_T(), rstart = wall_clock64();
+  unsigned long long tph = tstart;
+#endif
   // prologue: tile 0 landed (tiles 1, 2 may still be in flight: 8 instructions)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (ntiles > 0) { qk(sA, 0); skip = part1(sA, 0, alpha, msub); }
-  // one pipelined step: tile t is in `cur` (scores s'), tile t+1 goes into `nxt`
-  auto step = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], int t) {
-    // tile t+1 has landed in every wave's view after this wait + barrier (tile t+2 may be in flight); tile t-1's slot is free
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    dma_tile(t + 3);
-    const bool more = t + 1 < ntiles;
-    if (more) qk(nxt, t + 1);
-    const float al = alpha, ms = msub;
-    const bool sk = skip;
-    if (!sk) part2(cur, al, ms, pf);
-    if (!sk) pv(pf, t);
-    if (more) skip = part1(nxt, t + 1, alpha, msub);
+  if (nsub > 0) { qk(sA, 0); part1(sA, 0); }
+#ifdef USDM_ATTN_TRACE
+  ATR_ADD(5, tph);
+#endif
+
+  // ---- pipelined steps: sub-tile j is in `cur` (scores s', state alpha / msub / skip), sub-tile j+1 goes into `nxt`.
+  // BAR (odd j): sub-tile j+1 opens a new 64-key tile -> its tile must have landed in every wave's view (counted wait + barrier;
+  // tile kt+2 may be in flight), and the slot of tile kt-1 is free for tile kt+3.
+  auto top = [&](int j, auto BAR) {
+    if (__any(alpha != 1.0f)) {                                      // rare (deferred maximum): rescale the running state
+      l_run *= alpha;
+      // in place (inline asm pins source = destination): written as C++ the compiler puts the product in fresh registers and
+      // pays 32 register copies on the path that does NOT rescale, i.e. in every step
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[t][r]) : "v"(alpha));
+    }
+    if constexpr (decltype(BAR)::value) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      dma_tile(((j + 1) >> 1) + 2);
+    }
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(sA, sB, t);
-    if (t + 1 < ntiles) step(sB, sA, t + 1);
+  auto exp_pv = [&](f32x16& cur, int j, float ms) {                  // exp pass + P.V of sub-tile j
+    u32x4 vf[2][2];
+    load_v(vf, j);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __builtin_amdgcn_exp2f(cur[i] - ms);           // masked scores (-1e30) underflow to exactly 0
+      cur[i] = p;
+      ps += p;
+    }
+    l_run += ps;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pfr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pfr[e] = (__bf16)cur[8 * s2 + e];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[t][s2]), pfr, oacc[t], 0, 0, 0);
+    }
+  };
+  auto bias_fast = [&](f32x16& nxt, int jn) {                        // sub-tile jn wholly on the side cs_sign of the queries
+    const float ash = -cs_sign * slope2 * (float)(qpos - 32 * jn - 8 * lh);
+    float mloc = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { nxt[i] = fmaf(nxt[i], sc, cs[i]); mloc = fmaxf(mloc, nxt[i]); }
+    max_update(mloc + ash, ash);
+  };
+  // steady state, ONE basic block per call: S^T(j+1) || exp(j), then P.V(j) || bias / maximum (j+1)
+  auto hot = [&](f32x16& cur, f32x16& nxt, int j, auto BAR) {
+    top(j, BAR);
+    const float ms = msub;
+    qk(nxt, j + 1);
+    exp_pv(cur, j, ms);
+    bias_fast(nxt, j + 1);
+  };
+  // every other case (first / last sub-tiles, the sub-tiles around the diagonal, skipped sub-tiles)
+  auto slow = [&](f32x16& cur, f32x16& nxt, int j, auto BAR) {
+    top(j, BAR);
+    const bool more = j + 1 < nsub, sk = skip;
+    const float ms = msub;
+    const int sd = more ? side_of(j + 1) : 0;
+    if (sd != 0 && (float)sd != cs_sign) {                           // crossing the diagonal: flip the folded sign (once per wave)
+      cs_sign = (float)sd;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cs[i] = -cs[i];
+    }
+    if (more) qk(nxt, j + 1);
+    if (!sk) exp_pv(cur, j, ms);
+    if (more) {
+      if (sd != 0) bias_fast(nxt, j + 1);
+      else part1(nxt, j + 1);
+    }
+  };
+  // a PAIR of steps (j even: cur = sA at entry and at exit) can take the hot path when sub-tiles j+1 and j+2 both lie on the
+  // current side of the queries; the range of such j is [lo, hi) on the left of the diagonal and again on its right
+  const int jl_hi = min((qw0 - 31) / 32, nsub - 2);                  // left: 32 (j+2) + 31 <= qw0, and j + 2 < nsub with no masked key
+  const int jr_lo = (qw0 + 31 + 31) / 32 - 1;                        // right: 32 (j+1) >= qw0 + 31
+  const int full = kv_len / 32;                                      // sub-tiles without a masked key: indices < full
+  int j = 0;
+  while (j < nsub) {
+    const bool left_ok = j + 2 <= jl_hi + 1 && j + 2 < full && cs_sign > 0.f && j >= 0;
+    const bool right_ok = j + 1 >= jr_lo + 1 && j + 2 < full && cs_sign < 0.f;
+    if ((left_ok || right_ok) && !skip) {
+      hot(sA, sB, j, std::false_type{});
+      if (!skip) hot(sB, sA, j + 1, std::true_type{});
+      else slow(sB, sA, j + 1, std::true_type{});
+    } else {
+      slow(sA, sB, j, std::false_type{});
+      if (j + 1 < nsub) slow(sB, sA, j + 1, std::true_type{});
+    }
+    j += 2;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the trailing no-op DMA instructions)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the trailing no-op DMA instructions)
+#ifdef USDM_ATTN_TRACE
+  if (tid == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 4096) {
+      for (int i = 0; i < 6; ++i) g_attn_trace[wg * 8 + i] = atr[i];
+      g_attn_trace[wg * 8 + 6] = ATR_T() - tstart;
+      g_attn_trace[wg * 8 + 7] = wall_clock64() - rstart;
+    }
+  }
+#endif
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
