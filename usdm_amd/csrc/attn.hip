@@ -11,7 +11,6 @@
 // V is therefore consumed as V^T [d][key], which the producing GEMM epilogue writes directly.
 #include "common.h"
 #include <stdlib.h>
-#include <type_traits>
 #include "../../include/usdm_hip.h"
 
 namespace {
@@ -342,317 +341,6 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
       }
   }
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Voicebox attention, second form (head dim 64, bidirectional ALiBi): the same mathematics and the same orientation
-// (S^T = K.Q^T, P^T fed back from the accumulator registers) re-cut around what the first form's counters showed
-// (profiles/r01_gemm_ablation.txt: 13.7 VALU instructions per score, VALU issue 47 %, MFMA 13 %, nothing overlapped):
-//   * K and V^T tiles travel global -> LDS by LDS-DMA (buffer_load ... lds, 8 rows x 128 B per instruction, XOR swizzle on the
-//     source side) into a 4-slot ring, three tiles ahead: no staging registers, no per-tile address arithmetic (one scalar
-//     offset per tile), one barrier per 64-key tile;
-//   * the key rows of a 32-key sub-tile are PERMUTED on their way into the S^T MFMA (lane r multiplies key kappa(r), kappa = r
-//     with bits 2 and 3 swapped): accumulator registers 8s..8s+7 of lane half h then hold the 8 CONSECUTIVE keys
-//     16s + 8h .. +7, so the V^T operand of O^T += V^T.P^T is ONE ds_read_b128 of 8 consecutive keys - K and V^T share one LDS
-//     image and one conflict-free read pattern (the first form needed two ds_read_b64 per fragment and an image LDS-DMA cannot fill);
-//   * software pipeline inside the wave (one wave per SIMD) in steps of ONE 32-key sub-tile, so that the live state (two score
-//     tiles, O^T, fragments, constants) stays well inside the register file: S^T of sub-tile j+1 is on the matrix pipe while the
-//     VALU exponentiates sub-tile j, and O^T += V^T.P^T of sub-tile j runs under the bias / maximum pass of sub-tile j+1.  The
-//     steady-state step is ONE basic block (no branch between its MFMAs and its VALU work), which is what lets the compiler's
-//     scheduler interleave the two pipes;
-//   * the ALiBi term of a sub-tile that lies wholly on one side of the wave's queries is split into a per-register constant
-//     (folded into the scaling FMA) and a per-lane, per-step scalar that only shifts the running maximum: 1 FMA per score;
-//   * the running maximum is only raised when it grows by more than 2^4 (deferred rescale): the O^T rescale becomes a rare,
-//     wave-uniform branch at the top of a step instead of 32 multiplies in every step.  P <= 2^4 keeps the same relative
-//     precision in bf16, sums stay far inside f32 range.
-// Results differ from the first form by f32 summation order and by the (exact in the limit) deferred maximum.
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int kappa32(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
-
-__global__ __launch_bounds__(256) void attn_vb_kernel(const usdm_attn_args a) {
-  constexpr int DH = 64, NSL = 4, TILE = KT * 128;              // one operand tile: 64 rows x 128 B
-  constexpr int SLOT = 2 * TILE;                                 // K tile + V^T tile
-  constexpr float DEFER = 4.0f;                                  // log2 domain
-  __shared__ __attribute__((aligned(16))) char smem[NSL * SLOT];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane & 31, lh = lane >> 5;
-  const int qb = blockIdx.x;
-  const int lin = blockIdx.y + gridDim.y * blockIdx.z;
-  const int h = (int)gridDim.y - 1 - lin / (int)gridDim.z;       // flattest slope first (see attn_kernel)
-  const int b = lin % (int)gridDim.z;
-  const int hk = h / (a.Hq / a.Hkv);
-  const int q0 = qb * 128 + wv * 32;
-  const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
-  const int ntiles = (kv_len + KT - 1) / KT;
-  const int nsub = (kv_len + 31) / 32;                           // 32-key sub-tiles that hold at least one valid key
-
-  const bf16_t* Q = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
-  const bf16_t* K = (const bf16_t*)a.k + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs;
-  const bf16_t* V = (const bf16_t*)a.vt + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs;
-  auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, 0x80000000u, 0x00020000);
-  auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x80000000u, 0x00020000);
-
-  // ---- LDS-DMA: wave w moves row blocks 2w, 2w+1 (8 rows each) of the K tile and of the V^T tile.  LDS slot c' of row r
-  // receives logical 16-B piece c' ^ swz(r), swz(r) = (r >> 1) & 7: conflict-free ds_read_b128 for the 32x32x16 operand rows.
-  unsigned vofK[2], vofV[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (2 * wv + i) * 8 + (lane >> 3);
-    const int pc = (lane & 7) ^ ((r >> 1) & 7);
-    vofK[i] = (unsigned)r * (unsigned)(a.k_rs * 2) + (unsigned)(pc << 4);
-    vofV[i] = (unsigned)r * (unsigned)(a.v_ds * 2) + (unsigned)(pc << 4);
-  }
-  const unsigned OOB = 0xFFFFFFF0u;
-  auto dma_tile = [&](int kt) {          // always 4 instructions per wave (a tile past the end fetches nothing: counted waits stay exact)
-    char* sl = smem + (kt & (NSL - 1)) * SLOT;
-    const bool ok = kt < ntiles;
-    const unsigned soK = (unsigned)kt * (unsigned)(KT * a.k_rs * 2), soV = (unsigned)kt * (unsigned)(KT * 2);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(sl + (2 * wv + i) * 1024), 16,
-                                               ok ? vofK[i] : OOB, ok ? soK : 0u, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(sl + TILE + (2 * wv + i) * 1024), 16,
-                                               ok ? vofV[i] : OOB, ok ? soV : 0u, 0, 0);
-    }
-  };
-  dma_tile(0); dma_tile(1); dma_tile(2);
-
-  // Q fragments (B operand of S^T): lane holds Q[q0+lq][16s + 8*lh .. +7]
-  bf16x8 qf[4];
-  {
-    int qr = q0 + lq;
-    if (qr > a.Sq - 1) qr = a.Sq - 1;
-    const bf16_t* qp = Q + (int64_t)qr * a.q_rs + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + 16 * s));
-  }
-  // fragment byte offsets inside a 64-key tile image.  K operand of sub-tile u, d-step s: row 32u + kappa(lq), piece 2s + lh
-  // (row + 32 keeps the swizzle: + 4096 bytes).  V^T operand of d-tile t, key step s' of sub-tile u: row 32t + lq, piece
-  // 4u + 2s' + lh = (2s' + lh) ^ swz with bit 2 flipped by u: ^ 64 bytes.
-  unsigned foK[4], foV[2][2];
-  {
-    const int rk = kappa32(lq);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) foK[s] = rk * 128 + (((2 * s + lh) ^ ((rk >> 1) & 7)) << 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int rv = 32 * t + lq;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) foV[t][s] = TILE + rv * 128 + (((2 * s + lh) ^ ((rv >> 1) & 7)) << 4);
-    }
-  }
-  const int qpos = a.q_pos0 + q0 + lq;
-  const float slope = a.slopes ? a.slopes[h] : 0.f;
-  const float sc = a.scale * 1.4426950408889634f, slope2 = slope * 1.4426950408889634f;
-  // key of accumulator register i of sub-tile j in lane half lh: 32j + 8 lh + c(i), c(i) = 16(i >> 3) + (i & 7)
-  float cs[16];                                                      // sign * slope2 * c(i): the folded ALiBi constants
-#pragma unroll
-  for (int i = 0; i < 16; ++i) cs[i] = slope2 * (float)(16 * (i >> 3) + (i & 7));
-  float cs_sign = 1.0f;                                              // +1: sub-tiles to the left of the queries, -1: to the right
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const int qw0 = a.q_pos0 + q0;
-
-  // ---- building blocks (j = index of a 32-key sub-tile; its tile is j >> 1, its half u = j & 1)
-  auto qk = [&](f32x16& sa, int j) {                                 // S^T of sub-tile j
-    const char* sl = smem + ((j >> 1) & (NSL - 1)) * SLOT + (j & 1) * 4096;
-    u32x4 kf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *(const u32x4*)(sl + foK[s]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s]), qf[s], sa, 0, 0, 0);
-  };
-  auto load_v = [&](u32x4 (&vf)[2][2], int j) {
-    const char* sl = smem + ((j >> 1) & (NSL - 1)) * SLOT;
-    const unsigned x = (j & 1) ? 64u : 0u;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) vf[t][s] = *(const u32x4*)(sl + (foV[t][s] ^ x));
-  };
-  // the (deferred) maximum update shared by both forms of the bias pass: mloc = this lane's best TRUE score of the sub-tile
-  float alpha = 1.f, msub = 0.f;                                     // state handed from the bias pass of sub-tile j to its exp pass
-  bool skip = true;
-  auto max_update = [&](float mloc, float ash) {
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    skip = __all(mloc < m_run - 40.0f);                              // < 2^-34 of a denominator >= 1: invisible in f32 (see attn_kernel)
-    const float m_new = (mloc > m_run + DEFER) ? mloc : m_run;       // raise the maximum only for real growth: P <= 2^DEFER
-    alpha = __builtin_amdgcn_exp2f(m_run - m_new);                   // 1 when unchanged (also for a skippable sub-tile)
-    m_run = m_new;
-    msub = m_new - ash;
-  };
-  // general bias pass: any sub-tile (straddling the queries, key 0, masked tail); sa <- s' with true score = s' + ash
-  auto part1 = [&](f32x16& sa, int j) {
-    const int kbase = 32 * j + 8 * lh;
-    const float fq = (float)(qpos - kbase);
-    const float s00 = sa[0] * sc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float c = (float)(16 * (i >> 3) + (i & 7));
-      sa[i] = fmaf(sa[i], sc, -slope2 * fabsf(fq - c));
-    }
-    if (j == 0 && a.alibi_col0_zero && lh == 0) sa[0] = s00;         // key 0 carries no ALiBi bias (networks.py:327)
-    if (32 * j + 32 > kv_len) {                                      // keys past the sequence end (bucket padding): masked
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sa[i] = (kbase + 16 * (i >> 3) + (i & 7)) < kv_len ? sa[i] : -1e30f;
-    }
-    float mloc = -1e30f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, sa[i]);
-    max_update(mloc, 0.f);
-  };
-  // which side sub-tile j lies on for this wave: +1 left, -1 right, 0 straddling / special (key 0, masked tail)
-  auto side_of = [&](int j) -> int {
-    if (j <= 0 || 32 * j + 32 > kv_len) return 0;
-    if (32 * j + 31 <= qw0) return 1;
-    if (32 * j >= qw0 + 31) return -1;
-    return 0;
-  };
-
-  f32x16 sA, sB;
-#ifdef USDM_ATTN_TRACE
-  unsigned long long atr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long tstart = ATR_T(), rstart = wall_clock64();
-  unsigned long long tph = tstart;
-#endif
-  // prologue: tile 0 landed (tiles 1, 2 may still be in flight: 8 instructions)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  if (nsub > 0) { qk(sA, 0); part1(sA, 0); }
-#ifdef USDM_ATTN_TRACE
-  ATR_ADD(5, tph);
-#endif
-
-  // ---- pipelined steps: sub-tile j is in `cur` (scores s', state alpha / msub / skip), sub-tile j+1 goes into `nxt`.
-  // BAR (odd j): sub-tile j+1 opens a new 64-key tile -> its tile must have landed in every wave's view (counted wait + barrier;
-  // tile kt+2 may be in flight), and the slot of tile kt-1 is free for tile kt+3.
-  auto top = [&](int j, auto BAR) {
-    if (__any(alpha != 1.0f)) {                                      // rare (deferred maximum): rescale the running state
-      l_run *= alpha;
-      // in place (inline asm pins source = destination): written as C++ the compiler puts the product in fresh registers and
-      // pays 32 register copies on the path that does NOT rescale, i.e. in every step
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[t][r]) : "v"(alpha));
-    }
-    if constexpr (decltype(BAR)::value) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      dma_tile(((j + 1) >> 1) + 2);
-    }
-  };
-  auto exp_pv = [&](f32x16& cur, int j, float ms) {                  // exp pass + P.V of sub-tile j
-    u32x4 vf[2][2];
-    load_v(vf, j);
-    float ps = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float p = __builtin_amdgcn_exp2f(cur[i] - ms);           // masked scores (-1e30) underflow to exactly 0
-      cur[i] = p;
-      ps += p;
-    }
-    l_run += ps;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pfr;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pfr[e] = (__bf16)cur[8 * s2 + e];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[t][s2]), pfr, oacc[t], 0, 0, 0);
-    }
-  };
-  auto bias_fast = [&](f32x16& nxt, int jn) {                        // sub-tile jn wholly on the side cs_sign of the queries
-    const float ash = -cs_sign * slope2 * (float)(qpos - 32 * jn - 8 * lh);
-    float mloc = -1e30f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { nxt[i] = fmaf(nxt[i], sc, cs[i]); mloc = fmaxf(mloc, nxt[i]); }
-    max_update(mloc + ash, ash);
-  };
-  // steady state, ONE basic block per call: S^T(j+1) || exp(j), then P.V(j) || bias / maximum (j+1)
-  auto hot = [&](f32x16& cur, f32x16& nxt, int j, auto BAR) {
-    top(j, BAR);
-    const float ms = msub;
-    qk(nxt, j + 1);
-    exp_pv(cur, j, ms);
-    bias_fast(nxt, j + 1);
-  };
-  // every other case (first / last sub-tiles, the sub-tiles around the diagonal, skipped sub-tiles)
-  auto slow = [&](f32x16& cur, f32x16& nxt, int j, auto BAR) {
-    top(j, BAR);
-    const bool more = j + 1 < nsub, sk = skip;
-    const float ms = msub;
-    const int sd = more ? side_of(j + 1) : 0;
-    if (sd != 0 && (float)sd != cs_sign) {                           // crossing the diagonal: flip the folded sign (once per wave)
-      cs_sign = (float)sd;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) cs[i] = -cs[i];
-    }
-    if (more) qk(nxt, j + 1);
-    if (!sk) exp_pv(cur, j, ms);
-    if (more) {
-      if (sd != 0) bias_fast(nxt, j + 1);
-      else part1(nxt, j + 1);
-    }
-  };
-  // a PAIR of steps (j even: cur = sA at entry and at exit) can take the hot path when sub-tiles j+1 and j+2 both lie on the
-  // current side of the queries; the range of such j is [lo, hi) on the left of the diagonal and again on its right
-  const int jl_hi = min((qw0 - 31) / 32, nsub - 2);                  // left: 32 (j+2) + 31 <= qw0, and j + 2 < nsub with no masked key
-  const int jr_lo = (qw0 + 31 + 31) / 32 - 1;                        // right: 32 (j+1) >= qw0 + 31
-  const int full = kv_len / 32;                                      // sub-tiles without a masked key: indices < full
-  int j = 0;
-  while (j < nsub) {
-    const bool left_ok = j + 2 <= jl_hi + 1 && j + 2 < full && cs_sign > 0.f && j >= 0;
-    const bool right_ok = j + 1 >= jr_lo + 1 && j + 2 < full && cs_sign < 0.f;
-    if ((left_ok || right_ok) && !skip) {
-      hot(sA, sB, j, std::false_type{});
-      if (!skip) hot(sB, sA, j + 1, std::true_type{});
-      else slow(sB, sA, j + 1, std::true_type{});
-    } else {
-      slow(sA, sB, j, std::false_type{});
-      if (j + 1 < nsub) slow(sB, sA, j + 1, std::true_type{});
-    }
-    j += 2;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the trailing no-op DMA instructions)
-#ifdef USDM_ATTN_TRACE
-  if (tid == 0) {
-    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (wg < 4096) {
-      for (int i = 0; i < 6; ++i) g_attn_trace[wg * 8 + i] = atr[i];
-      g_attn_trace[wg * 8 + 6] = ATR_T() - tstart;
-      g_attn_trace[wg * 8 + 7] = wall_clock64() - rstart;
-    }
-  }
-#endif
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  const int qr = q0 + lq;
-  if (qr < a.Sq) {
-    bf16_t* op = (bf16_t*)a.o + (int64_t)b * a.o_bs + (int64_t)qr * a.o_rs + h * DH;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * t + 8 * g + 4 * lh;
-        uint2 o;
-        o.x = pack_bf2(oacc[t][4 * g + 0] * inv, oacc[t][4 * g + 1] * inv);
-        o.y = pack_bf2(oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
-        *(uint2*)(op + d) = o;
-      }
-  }
-}
 }  // namespace
 
 #ifdef USDM_ATTN_TRACE
@@ -687,14 +375,6 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
     if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a);        \
     else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a);              \
   } while (0)
-  // Voicebox shape: the LDS-DMA / software-pipelined form (USDM_ATTN_V2=0 restores the first form for A/B runs)
-  const int v2 = getenv("USDM_ATTN_V2") ? atoi(getenv("USDM_ATTN_V2")) : 1;   // (read per call: tests compare the two forms in one process)
-  if (a.dh == 64 && a.mode == 0 && v2 && !small && a.Hq % a.Hkv == 0 && (a.k_rs * 2) % 16 == 0 && (a.v_ds * 2) % 16 == 0 &&
-      (int64_t)cdiv(a.Skv, KT) * KT * a.k_rs * 2 < 0x7FFFFF00ll && (int64_t)64 * a.v_ds * 2 < 0x7FFFFF00ll) {
-    hipLaunchKernelGGL(attn_vb_kernel, dim3(cdiv(a.Sq, 128), a.Hq, a.B), dim3(256), 0, st, a);
-    USDM_LAUNCH_CHECK();
-    return 0;
-  }
   if (a.dh == 64 && a.mode == 0) USDM_ATTN(64, 0);
   else if (a.dh == 64) USDM_ATTN(64, 1);
   else if (a.mode == 0) USDM_ATTN(128, 0);
