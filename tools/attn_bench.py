@@ -1,5 +1,5 @@
-"""Voicebox attention launch time (S=1118, 2 x 16 heads, d=64), first form vs the LDS-DMA / pipelined form, hipGraph replay of
-24 launches over 24 distinct Q/K/V sets (as in the 24-layer stack)."""
+"""Voicebox attention launch time (default S=1118, 2 x 16 heads, d=64; AB_B / AB_H / AB_S override), hipGraph replay of 24 launches
+over 24 distinct Q/K/V sets (as in the 24-layer stack)."""
 import os
 import sys
 import torch
@@ -18,8 +18,7 @@ H = nh * 64
 slopes = torch.tensor([2 ** (-(i + 1) / 2) for i in range(nh)], device=dev)
 kvl = torch.tensor([S] * Bx, dtype=torch.int32, device=dev)
 outs = {}
-for v2 in ("0", "1"):
-    os.environ["USDM_ATTN_V2"] = v2
+for v2 in ("-",):
     o = torch.zeros(Bx * S, H, device=dev, dtype=bf)
     plan = ops.Plan()
     for i in range(L):
@@ -37,7 +36,4 @@ for v2 in ("0", "1"):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (10 * L)
     fl = 4 * Bx * nh * S * S * 64
-    print(f"USDM_ATTN_V2={v2}: {us:6.2f} us per launch  ({fl / us / 1e6:5.0f} TF/s)", flush=True)
-    outs[v2] = o.float().clone()
-d = (outs["0"] - outs["1"]).abs()
-print(f"max |v1 - v2| {d.max().item():.4f} (max |o| {outs['0'].abs().max().item():.3f}), mean {d.mean().item():.2e}")
+    print(f"B={Bx} H={nh} S={S}: {us:6.2f} us per launch  ({fl / us / 1e6:5.0f} TF/s)", flush=True)

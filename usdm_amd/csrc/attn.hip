@@ -159,6 +159,9 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
     const int kt = grp + KS * it;
     const char* sK = smem + (it & 1) * STAGE;
     const char* sV = sK + KT * KROW;
+    // a wave whose 32 queries all lie past the end (the last query block of S = 1118: queries 1120..1151) only helps with the
+    // loads: its multiplies and exponentials would take vector issue slots from the co-resident workgroup for nothing
+    if (q0 < a.Sq) {
 
     // ---- S^T = K . Q^T for the two 32-key sub-tiles
     f32x16 sacc[2];
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
         }
       }
     }
+    }   // (active wave)
     ATR_ADD(3, tph);
     if (it + 1 < myn) store_tile((it + 1) & 1);
     if (it + 2 < myn) load_tile(kt + 2 * KS);
