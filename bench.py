@@ -93,6 +93,17 @@ class Pipeline:
                 del old
                 comm.close()
                 self.tp_comm = f"rccl (p2p in-situ check failed: {why})"
+        # Voicebox: the two classifier-free-guidance halves of every NFE on a PAIR of ranks (optional row): ranks
+        # (2i, 2i+1) evaluate the unconditional / conditional estimator at batch 1 and all-gather the [1,80,S] velocities, instead
+        # of every rank repeating the batch-2 estimator.  Even world sizes only; USDM_VB_CFG_SPLIT=0 switches it off.
+        self.cfg_group, self.vb_mode = None, "replica (CFG batch 2 on every rank)"
+        if world > 1 and world % 2 == 0 and os.environ.get("USDM_VB_CFG_SPLIT", "1") == "1":
+            import torch.distributed as dist
+            for i in range(0, world, 2):                      # every rank creates every pair group (new_group is collective)
+                g2 = dist.new_group([i, i + 1])
+                if rank in (i, i + 1):
+                    self.cfg_group = g2
+            self.vb_mode = "CFG halves on rank pairs (2i: unconditional, 2i+1: conditional), one all-gather per NFE"
         self.vb = synth.make_voicebox(dev)
         self.voc = synth.make_bigvgan(dev, compute_dtype=torch.float32 if args.vocoder_dtype == "f32" else torch.bfloat16)
         torch.cuda.synchronize()
@@ -164,7 +175,8 @@ class Pipeline:
         self._mark("llm3")
         agent_units = (o3[0, p3.shape[1]:] - 32002).clamp_(0, 9999)
         audio = self.mu.reconstruct_speech(agent_units, dev, None, self.ue, self.vb, self.voc, n_timesteps=a.nt,
-                                           reference_mel=self.ref_mel, reference_unit=self.ref_units, noise=self.noise)
+                                           reference_mel=self.ref_mel, reference_unit=self.ref_units, noise=self.noise,
+                                           cfg_group=self.cfg_group)
         self._mark("dec")
         self.prompt_lens = (p1.shape[1], p2.shape[1], p3.shape[1])
         self.n_generated = 2 * a.text_tokens + a.units
@@ -463,7 +475,7 @@ def main():
                                "Token-Voicebox 63 NFE (Heun, CFG, 3 s prompt) -> BigVGAN",
                    "wave_samples": 160000, "prompt_tokens": list(pipe.prompt_lens), "generated_tokens": pipe.n_generated,
                    "voicebox_n_timesteps": args.nt, "mel_frames": pipe.frames, "output_samples": int(audio.shape[0]),
-                   "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm,
+                   "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm, "voicebox": pipe.vb_mode,
                    **({"shared_gpu_validation": f"{world} ranks on {torch.cuda.device_count()} GPU(s): code-path validation, not a scaling result"}
                       if os.environ.get("USDM_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count() else {})},
         "llm_tokens_per_s": round(pipe.n_generated / (llm_ms * 1e-3), 2),

@@ -34,10 +34,15 @@ class CFM(BaseModule):
 
     @torch.no_grad()
     def generate(self, x, cond, cond_lengths, n_timesteps, solver="euler", gradient_scale=0.0, speech_prompt=False,
-                 prompt_lengths=None, noise=None, trace=None):
+                 prompt_lengths=None, noise=None, trace=None, cfg_group=None):
         """x int64 [B,S], cond f32 [B,80,S], cond_lengths int64 [B] -> f32 [B,80,S]
         (reference: voicebox.py:140-150 with solve_euler :74-99 / solve_heun :101-138 and the CFG of :51-72).
-        trace (tests only): a list that receives a copy of the raw estimator output of every NFE."""
+        trace (tests only): a list that receives a copy of the raw estimator output of every NFE.
+        cfg_group (optional): a torch.distributed group of exactly TWO ranks that hold the same model and are called
+        with the same arguments (and the same `noise`).  The classifier-free-guidance doubling of voicebox.py:60-65 is then split
+        over the pair: group rank 0 evaluates the unconditional half (null tokens, zero cond), group rank 1 the conditional half,
+        each at batch B instead of 2B; one all-gather of the [B,80,S] velocities per NFE rebuilds the [2B,80,S] estimator output
+        and both ranks apply the same solver update (v_c + gs (v_c - v_u)), so both return the same mel."""
         if solver not in ("euler", "heun"):
             return None  # the reference falls through and returns None for unknown solvers
         if not cond.is_cuda:
@@ -63,15 +68,45 @@ class CFM(BaseModule):
         # condition are zero-padded to the bucket's frame count Sb and the true lengths go to the kernels through kv_len.
         Sb = self.estimator.bucket_frames(S)
         ragged = ragged or Sb != S
-        gp, io = self.estimator.get_plan(B, Sb, 2 if cfg else 1, bool(speech_prompt), dev, ragged)
+        split = cfg and cfg_group is not None
+        half, gather = 0, None
+        if split:
+            import torch.distributed as dist
+            if dist.get_world_size(cfg_group) != 2:
+                raise ValueError("cfg_group must hold exactly two ranks (unconditional half, conditional half)")
+            half = dist.get_rank(cfg_group)
+            staged = dist.get_backend(cfg_group) == "gloo"        # validation runs (ranks sharing a GPU): through host memory
+
+            def gather(dst, src):
+                if staged:
+                    c = torch.empty(dst.shape, dtype=dst.dtype)
+                    dist.all_gather_into_tensor(c, src.cpu(), group=cfg_group)
+                    dst.copy_(c)
+                else:
+                    dist.all_gather_into_tensor(dst, src, group=cfg_group)
+        # the unconditional half is the estimator on null tokens with a zero condition (voicebox.py:60-65): the plan of a split
+        # rank is the batch-B plan with (use_cond = False, ids = null) or (use_cond as given, real ids)
+        use_cond = bool(speech_prompt) and not (split and half == 0)
+        gp, io = self.estimator.get_plan(B, Sb, 2 if (cfg and not split) else 1, use_cond, dev, ragged)
         vl = (cond_lengths + 1).to(torch.int32)
-        io["kv_len"].copy_(torch.cat([vl, vl]) if cfg else vl)
+        io["kv_len"].copy_(torch.cat([vl, vl]) if (cfg and not split) else vl)
         if Sb != S:
             io["ids"].zero_(); io["cond"].zero_()
             noise = torch.nn.functional.pad(noise, (0, Sb - S))
-        io["ids"][:, :S].copy_(x)
-        io["cond"][:, :, :S].copy_(cond)
-        condf = io["cond"]
+        if split and half == 0:
+            io["ids"].fill_(self.n_tokens)                    # the null token (estimator vocabulary = n_tokens + 1)
+        else:
+            io["ids"][:, :S].copy_(x)
+        # the solver's cond (prompt re-noising, voicebox.py:115-117) is the caller's cond on BOTH ranks; a split rank keeps it
+        # apart from the estimator's cond input, which is never read on the unconditional rank (use_cond = False)
+        if split:
+            condf = torch.zeros_like(io["cond"])
+            condf[:, :, :S].copy_(cond)
+            io["cond"].copy_(condf)
+            vout2 = torch.zeros(2 * B, F_, Sb, device=dev, dtype=torch.float32)
+        else:
+            io["cond"][:, :, :S].copy_(cond)
+            condf = io["cond"]
         Z = noise[0].clone()
         v1 = torch.empty_like(Z)
         io["y"].copy_(Z)
@@ -80,13 +115,20 @@ class CFM(BaseModule):
         t_span = torch.linspace(0, 1, n + 1)
         t, dt = t_span[0], t_span[1] - t_span[0]
         io["t"].fill_(float(t))
-        Bx = B * (2 if cfg else 1)
+        Bx = B * (2 if (cfg and not split) else 1)       # batch rows of THIS rank's estimator plan (their time inputs)
         k = 1
         common = dict(B=B, F=F_, S=S, cfg=cfg, gs=float(gradient_scale), z_in=io["y"], t_cur=io["t"], t_count=Bx, cond=condf, P=P)
-        for steps in range(1, n + 1):
+        def estimator_out():
             gp.run()
+            if not split:
+                return io["out"]
+            gather(vout2, io["out"])                          # [uncond ; cond], the order the solver kernel's CFG combine expects
+            return vout2
+
+        for steps in range(1, n + 1):
+            vout = estimator_out()
             if trace is not None:
-                trace.append(io["out"][:, :, :S_true].clone())
+                trace.append(vout[:, :, :S_true].clone())
             t = t + dt
             c_eps, c_cond = float(1 - (1 - self.sigma_min) * t), float(t)
             last = steps == n
@@ -94,16 +136,16 @@ class CFM(BaseModule):
             eps = None
             if speech_prompt:
                 eps, k = noise[k], k + 1
-            ops.vb_solver_step(io["out"], Z, mode=0, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
+            ops.vb_solver_step(vout, Z, mode=0, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
                                z_commit=None if do_corr else Z, t_next=float(t), **common)
             if do_corr:
-                gp.run()
+                vout = estimator_out()
                 if trace is not None:
-                    trace.append(io["out"][:, :, :S_true].clone())
+                    trace.append(vout[:, :, :S_true].clone())
                 eps = None
                 if speech_prompt:
                     eps, k = noise[k], k + 1
-                ops.vb_solver_step(io["out"], Z, mode=1, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
+                ops.vb_solver_step(vout, Z, mode=1, dt=float(dt), v1=v1, eps=eps, c_eps=c_eps, c_cond=c_cond,
                                    z_commit=Z, t_next=float(t), **common)
             if not last:
                 dt = t_span[steps + 1] - t

@@ -69,11 +69,12 @@ def initialize_decoder(model_cache_dir, device):
 
 @torch.inference_mode()
 def reconstruct_speech(agent_unit, device, reference_path, token_extractor, voicebox, vocoder, n_timesteps=50,
-                       reference_mel=None, reference_unit=None, noise=None):
+                       reference_mel=None, reference_unit=None, noise=None, cfg_group=None):
     """units -> waveform float32 numpy [256 * frames] (model_util.py:72-105).
 
     With a speech prompt, supply `reference_unit` (50 Hz ids of the prompt, e.g. from
-    token_extractor.predict) and `reference_mel` ([1, 80, frames] log-mel, un-normalised)."""
+    token_extractor.predict) and `reference_mel` ([1, 80, frames] log-mel, un-normalised).
+    cfg_group: see Voicebox.generate (the two CFG halves on two ranks; both ranks must then pass the same `noise`)."""
     agent_unit, _ = process_unit(agent_unit, vocoder.h, device)
     if reference_path is not None and reference_mel is None:
         # reference prompt from a wav file, as the reference does (model_util.py:76-82); file decode + 16 kHz resampling are host I/O
@@ -94,13 +95,13 @@ def reconstruct_speech(agent_unit, device, reference_path, token_extractor, voic
         prompt_lengths = torch.LongTensor([P]).to(device)
         unit = torch.cat([reference_unit, agent_unit], dim=-1)
         y_dec = voicebox.generate(unit, dummy_y, dummy_y_lengths, n_timesteps=n_timesteps, solver="heun", gradient_scale=1.0,
-                                  speech_prompt=True, prompt_lengths=prompt_lengths, noise=noise)
+                                  speech_prompt=True, prompt_lengths=prompt_lengths, noise=noise, cfg_group=cfg_group)
         y_dec = y_dec[:, :, P:]
     else:
         dummy_y = torch.zeros(agent_unit.shape[0], vocoder.h.num_mels, agent_unit.shape[-1], device=device)
         dummy_y_lengths = torch.LongTensor([dummy_y.shape[-1]]).to(device)
         y_dec = voicebox.generate(agent_unit, dummy_y, dummy_y_lengths, n_timesteps=n_timesteps, solver="heun",
-                                  gradient_scale=1.0, speech_prompt=False, noise=noise)
+                                  gradient_scale=1.0, speech_prompt=False, noise=noise, cfg_group=cfg_group)
     # inverse normalisation is folded into the vocoder's layout kernel (y*std + mean, model_util.py:103)
     audio_dec = vocoder.forward(y_dec.contiguous(), mel_std, mel_mean).cpu().squeeze().clamp(-1, 1).numpy()
     return audio_dec
