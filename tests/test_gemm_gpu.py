@@ -330,3 +330,53 @@ def test_pingpong_selected_for_big_linear(dev):
     o = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
     ops.gemm(A, W, M=M, N=N, Kc=K, out16=o)
     _check(o.float(), A.double().cpu() @ W.double().cpu().T, torch.bfloat16, K, "big linear")
+
+
+@pytest.mark.parametrize("M", [2236, 1118, 300])
+def test_folded_layernorm_producer_and_consumers(dev, M, tile_env):
+    """LayerNorm folded into the neighbouring GEMM epilogues (usdm_gemm stats_out / ln_mode; the post-LN block of the reference,
+    networks.py:236-266).  Producer: per-tile row sums equal the sums of the f32 output it stored.  Consumer 1 (GELU epilogue):
+    GELU(LN(x) W0^T + b) from the un-normalised bf16 rows and gamma-folded weights.  Consumer 2: residual = LN(x) computed on the
+    fly from the un-normalised f32 rows, also under split-K (only split 0 adds it).  All three on every ping-pong tile."""
+    from usdm_amd import ops
+    from usdm_amd._lib import ACT_GELU, UsdmError
+    H, I = 1024, 512
+    bf = torch.bfloat16
+    for tile in (12, 13, 14):
+        tile_env(tile)
+        # ---- producer: x1 = A Wo^T + b + res, stats of x1
+        A, Wo = _rand((M, H), bf, 41, 0.3).to(dev), _rand((H, H), bf, 42, 0.05).to(dev)
+        b, res = _rand((H,), torch.float32, 43).to(dev), _rand((M, H), torch.float32, 44, 2.0).to(dev) + 0.7
+        x32 = torch.zeros(M, H, device=dev); x16 = torch.zeros(M, H, device=dev, dtype=bf)
+        nt = H // 128
+        st = torch.full((M, nt, 2), float("nan"), device=dev)
+        ops.gemm(A, Wo, M=M, N=H, Kc=H, bias=b, residual=res, ldr=H, out32=x32, out16=x16, stats_out=st)
+        xs = x32.double().view(M, nt, 128)
+        assert torch.allclose(st[:, :, 0].double(), xs.sum(-1), rtol=1e-5, atol=1e-3), f"tile {tile}: row sums"
+        assert torch.allclose(st[:, :, 1].double(), (xs * xs).sum(-1), rtol=1e-5, atol=1e-3), f"tile {tile}: row sums of squares"
+        assert torch.equal(x16, x32.to(bf))
+        # ---- consumer 1: GELU(LN(x1) W1^T + b1)
+        gam, bet = (1 + 0.2 * _rand((H,), torch.float32, 45)).to(dev), (0.3 * _rand((H,), torch.float32, 46)).to(dev)
+        W1, b1 = _rand((I, H), torch.float32, 47, 0.05).to(dev), _rand((I,), torch.float32, 48).to(dev)
+        w1g = (W1 * gam[None]).to(bf).contiguous()
+        c1, d1 = w1g.float().sum(1).contiguous(), (b1 + W1 @ bet).contiguous()
+        f16 = torch.zeros(M, I, device=dev, dtype=bf)
+        lnk = dict(stats=st, nt=nt, C=H, eps=1e-5)
+        ops.gemm(x16, w1g, M=M, N=I, Kc=H, bias=d1, act=ACT_GELU, out16=f16, ln=dict(mode=1, c=c1, **lnk))
+        ln = torch.nn.functional.layer_norm(x32.double(), (H,), gam.double(), bet.double(), 1e-5)
+        ref = torch.nn.functional.gelu(ln @ W1.double().T + b1.double())
+        err = (f16.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-2, f"tile {tile}: folded LN + GELU rel err {err}"
+        # ---- consumer 2: y = F W2^T + b2 + LN(x1), split-K 3 (bias and residual applied once)
+        F_, W2, b2 = _rand((M, I), bf, 49, 0.3).to(dev), _rand((H, I), bf, 50, 0.05).to(dev), _rand((H,), torch.float32, 51).to(dev)
+        for S in (1, 3):
+            parts = torch.full((max(S, 1), M, H), float("nan"), device=dev)
+            ops.gemm(F_, W2, M=M, N=H, Kc=I, bias=b2, residual=x32, ldr=H, out32=parts, split_k=S if S > 1 else 0, c_split_stride=M * H,
+                     ln=dict(mode=2, gamma=gam, beta=bet, **lnk))
+            ref2 = F_.double() @ W2.double().T + b2.double() + ln
+            err2 = (parts.sum(0).double() - ref2).abs().max().item() / ref2.abs().max().item()
+            assert err2 <= 1e-4, f"tile {tile}, split {S}: folded-LN residual rel err {err2}"
+    # a tile without the folded epilogues must refuse, not silently ignore
+    tile_env(5)
+    with pytest.raises(UsdmError):
+        ops.gemm(A, Wo, M=M, N=H, Kc=H, bias=b, out32=x32, stats_out=st)

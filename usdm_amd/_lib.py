@@ -43,6 +43,8 @@ class GemmArgs(C.Structure):
         ("qkv_S", C.c_int32), ("qkv_Spad", C.c_int32), ("qkv_H", C.c_int32), ("qkv_D", C.c_int32),
         ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_v", C.c_void_p),
         ("split_k", C.c_int32), ("c_split_stride", C.c_int64),
+        ("stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_nt", C.c_int32), ("ln_mode", C.c_int32), ("ln_C", C.c_int32),
+        ("ln_eps", C.c_float), ("ln_c", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
     ]
 
 

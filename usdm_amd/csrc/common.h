@@ -63,6 +63,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// sum over the 32-lane half of the wave this lane belongs to (lanes 0-31 / 32-63): wave_sum without its last step
+__device__ __forceinline__ float half_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_mov<0xB1>(v));
   v = fmaxf(v, dpp_mov<0x4E>(v));

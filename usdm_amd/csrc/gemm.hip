@@ -80,6 +80,22 @@ __device__ unsigned long long g_gemm_trace[8192 * 8];
     }                                                                                                                       \
     if (tr_mode)                                                                                                            \
       for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;                       \
+    if constexpr (PP) {                                                                                                     \
+      if (a.ln_mode) {   /* folded LayerNorm: (rstd, rstd * mean) of this tile's rows from the producer's per-tile partial sums */ \
+        for (int i = tid; i < BM; i += NTH) {                                                                               \
+          const int m = m0 + i;                                                                                             \
+          float s1 = 0.f, s2 = 0.f;                                                                                         \
+          if (m < a.M) {                                                                                                    \
+            const float* sp = a.ln_stats + ((int64_t)bz * a.c_bstride + m) * a.ln_nt * 2;                                   \
+            for (int t = 0; t < a.ln_nt; ++t) { s1 += sp[2 * t]; s2 += sp[2 * t + 1]; }                                     \
+          }                                                                                                                 \
+          const float mean = s1 / (float)a.ln_C;                                                                            \
+          const float var = fmaxf(s2 / (float)a.ln_C - mean * mean, 0.f);                                                   \
+          const float rstd = rsqrtf(var + a.ln_eps);                                                                        \
+          rowst[2 * i] = rstd; rowst[2 * i + 1] = rstd * mean;                                                              \
+        }                                                                                                                   \
+      }                                                                                                                     \
+    }                                                                                                                       \
   } while (0)
 
 template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2, bool PP = false>
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int SMEM = (NST * STAGE > EPI) ? NST * STAGE : EPI;
   // ONE LDS object (staging ring / epilogue tile + the per-column bias of the transposed epilogues): a second __shared__ array
   // beside an LDS-DMA ring can make hipcc drain the ring (vmcnt(0)) before every fragment read
-  __shared__ __attribute__((aligned(16))) char smem[SMEM + BN * 4];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + BN * 4 + (PP ? BM * 8 : 0)];   // + (rstd, rstd * mean) per row of the folded LayerNorm (ping-pong tiles)
 
   const int tid = threadIdx.x;
   TR(0);
@@ -200,6 +216,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // their per-column bias is staged in LDS (visible after the K loop's barriers)
   const bool tr_mode = a.transpose_out != 0 || (a.epi == USDM_EPI_QKV_HEADS && n0 >= 2 * a.qkv_H * a.qkv_D);
   float* sb = (float*)(smem + SMEM);
+  float* rowst = sb + BN;   // [BM][2], ping-pong tiles only
   if constexpr (!PP) USDM_GEMM_FETCH_BIAS();   // the ping-pong variants fetch it behind their first LDS-DMA instead
 
   f32x4 acc[TM][TN];
@@ -733,6 +750,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     const int64_t rstep = (int64_t)RPI * a.c_row_mul;
     int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
     const f32x2_t b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]};
+    f32x2_t lc01 = {0.f, 0.f}, lc23 = {0.f, 0.f};
+    if (a.ln_mode == 1) { const float4 c4 = *(const float4*)(a.ln_c + gcol + n); lc01 = f32x2_t{c4.x, c4.y}; lc23 = f32x2_t{c4.z, c4.w}; }
     float4 cv = *(const float4*)(ct + er * CST + ec);
 #pragma unroll 2
     for (int it = 0; it < NIT; ++it, row += rstep) {
@@ -740,7 +759,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       if (m0 + r >= a.M) break;
       const f32x2_t v01 = {cv.x, cv.y}, v23 = {cv.z, cv.w};
       if (it + 1 < NIT) cv = *(const float4*)(ct + (r + RPI) * CST + ec);
-      const f32x2_t g01 = gelu_erf2(v01 * a.alpha + b01), g23 = gelu_erf2(v23 * a.alpha + b23);
+      f32x2_t g01, g23;
+      if (a.ln_mode == 1) {          // folded LayerNorm: rstd * acc - rstd * mean * c[n] + bias'[n]
+        const float2 rs = *(const float2*)(rowst + 2 * r);
+        const f32x2_t r2 = {rs.x, rs.x}, nrm2 = {-rs.y, -rs.y};
+        g01 = gelu_erf2(fma2(v01, r2, fma2(lc01, nrm2, b01)));
+        g23 = gelu_erf2(fma2(v23, r2, fma2(lc23, nrm2, b23)));
+      } else {
+        g01 = gelu_erf2(v01 * a.alpha + b01); g23 = gelu_erf2(v23 * a.alpha + b23);
+      }
       uint2 p; p.x = pack_bf2v(g01); p.y = pack_bf2v(g23);
       *(uint2*)((bf16_t*)a.C16 + row * a.ldc + gcol + n) = p;
     }
@@ -789,6 +816,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     const bool has_res = resid != nullptr;
     const int64_t rstep = (int64_t)RPI * a.c_row_mul;
     int64_t row = ((int64_t)bz * a.c_bstride + m0 + er) * a.c_row_mul + a.c_row_off;
+    // folded LayerNorm, residual form (ln_mode 2): the residual rows are un-normalised x; LN(x) = x * (rstd gamma) - (rstd mean) gamma + beta
+    float lg[4] = {0.f, 0.f, 0.f, 0.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool ln_res = PP && a.ln_mode == 2 && has_res;
+    if (ln_res) {
+      const float4 g4 = *(const float4*)(a.ln_gamma + gcol + n), b4 = *(const float4*)(a.ln_beta + gcol + n);
+      lg[0] = g4.x; lg[1] = g4.y; lg[2] = g4.z; lg[3] = g4.w; lb[0] = b4.x; lb[1] = b4.y; lb[2] = b4.z; lb[3] = b4.w;
+    }
+    float* stp = (PP && C4 == 32 && a.stats_out) ? a.stats_out : nullptr;      // producer form: per-row partial sums of this tile's columns
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += NB) {
       float4 rres[NB];
@@ -820,11 +855,23 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           if (rbf) v[e] = round_bf(v[e]);
         }
         if (has_res) {
-          v[0] += rres[u].x; v[1] += rres[u].y; v[2] += rres[u].z; v[3] += rres[u].w;
+          if (ln_res) {
+            const float2 rs = *(const float2*)(rowst + 2 * r);
+            const float xr[4] = {rres[u].x, rres[u].y, rres[u].z, rres[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += fmaf(xr[e], rs.x * lg[e], fmaf(-rs.y, lg[e], lb[e]));
+          } else {
+            v[0] += rres[u].x; v[1] += rres[u].y; v[2] += rres[u].z; v[3] += rres[u].w;
+          }
           if (rbf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
           }
+        }
+        if (stp) {   // the 32 threads that share this row are one half of a wave: reduce, one 8-byte store per row and tile
+          const float s1 = half_sum((v[0] + v[1]) + (v[2] + v[3]));
+          const float s2 = half_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+          if ((tid & 31) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
         }
         const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
         if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
@@ -963,6 +1010,18 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
+  if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
+    USDM_CHECK_ARG(sel >= 12 && sel <= 14 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
+                       a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
+                   "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
+    USDM_CHECK_ARG(!a.stats_out || (a.act == USDM_ACT_NONE && a.split_k <= 1), "usdm_gemm: stats_out needs a plain, unsplit epilogue");
+    USDM_CHECK_ARG(a.ln_mode == 0 || (a.ln_stats && a.ln_nt > 0 && a.ln_nt <= 64 && a.ln_C > 0), "usdm_gemm: ln_stats / ln_nt / ln_C");
+    USDM_CHECK_ARG(a.ln_mode != 1 || (a.ln_c && a.act == USDM_ACT_GELU && a.C16 && !a.C32 && !a.residual && a.alpha == 1.0f && a.split_k <= 1),
+                   "usdm_gemm: ln_mode 1 is the GELU bf16-out epilogue (no residual, alpha 1)");
+    USDM_CHECK_ARG(a.ln_mode != 2 || (a.ln_gamma && a.ln_beta && a.residual && a.res_dtype == USDM_F32 && a.act == USDM_ACT_NONE && (a.ldr & 3) == 0),
+                   "usdm_gemm: ln_mode 2 needs an f32 residual, gamma / beta and a plain epilogue");
+    USDM_CHECK_ARG(a.ln_mode >= 0 && a.ln_mode <= 2, "usdm_gemm: ln_mode");
+  }
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
     if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);

@@ -73,7 +73,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
          a_tap_stride=0, ldw=None, groups=1, batch=1, a_gstride=0, w_gstride=0, a_bstride=0, c_gcol=0,
          c_bstride=0, bias=None, alpha=1.0, act=0, round_bf16=False, residual=None, ldr=0,
          out32=None, out16=None, ldc=None, c_row_mul=1, c_row_off=0, transpose_out=False,
-         qkv=None, split_k=0, c_split_stride=0, plan=None):
+         qkv=None, split_k=0, c_split_stride=0, stats_out=None, ln=None, plan=None):
     """Raw launch of usdm_gemm; see include/usdm_hip.h for the meaning of every field."""
     _need_cuda(A, W, bias, residual, out32, out16)
     a = GemmArgs()
@@ -94,6 +94,11 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
     a.ldc = ldc if ldc is not None else N
     a.c_row_mul, a.c_row_off, a.transpose_out = c_row_mul, c_row_off, int(transpose_out)
     a.split_k, a.c_split_stride = split_k, c_split_stride
+    a.stats_out = _ptr(stats_out)
+    if ln is not None:      # folded LayerNorm (include/usdm_hip.h): dict(mode, stats, nt, C, eps, c= | gamma=, beta=)
+        _need_cuda(ln["stats"], ln.get("c"), ln.get("gamma"), ln.get("beta"))
+        a.ln_stats, a.ln_nt, a.ln_mode, a.ln_C, a.ln_eps = _ptr(ln["stats"]), ln["nt"], ln["mode"], ln["C"], ln.get("eps", 1e-5)
+        a.ln_c, a.ln_gamma, a.ln_beta = _ptr(ln.get("c")), _ptr(ln.get("gamma")), _ptr(ln.get("beta"))
     if qkv is not None:
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]

@@ -163,7 +163,15 @@ class Transformer(nn.Module):
             at, sc = lay.attention, lay.attention.scaling
             wqkv = torch.cat([g(at.q_proj.weight) * sc, g(at.k_proj.weight), g(at.v_proj.weight)], 0)
             bqkv = torch.cat([g(at.q_proj.bias) * sc, g(at.k_proj.bias), g(at.v_proj.bias)], 0)
+            # LayerNorm 1 folded into the feed-forward GEMMs (usdm_gemm ln_mode; bf16 plan only): W1' = W1 * gamma1 along K,
+            # c1[n] = sum_k W1'[n][k] (of the ROUNDED operand the MFMA sees), d1 = b1 + W1 beta1
+            g1, be1 = g(lay.layer_norm.weight), g(lay.layer_norm.bias)
+            w1f = g(lay.feed_forward.intermediate_dense.weight)
+            w1g = (w1f * g1[None, :]).to(bf).contiguous()
+            fold = dict(w1g=w1g, c1=w1g.float().sum(1).contiguous(),
+                        d1=(g(lay.feed_forward.intermediate_dense.bias) + w1f @ be1).contiguous()) if bf == torch.bfloat16 else {}
             P["layers"].append(dict(
+                **fold,
                 wqkv=wqkv.to(bf).contiguous(), bqkv=bqkv.contiguous(),
                 wo=g(at.out_proj.weight).to(bf).contiguous(), bo=g(at.out_proj.bias).contiguous(),
                 ln1=(g(lay.layer_norm.weight).contiguous(), g(lay.layer_norm.bias).contiguous()),
@@ -241,6 +249,12 @@ class Transformer(nn.Module):
         nbuf = max(nsp if use_split else 0, wo_split)
         split2 = plan.hold(torch.zeros(nbuf, R, H, device=dev, dtype=torch.float32)) if nbuf else None
 
+        # LayerNorm 1 folded into the out-proj / FFN1 / FFN2 epilogues (no launch, no 22 MB round trip): USDM_VB_LN_FOLD=0 restores
+        # the separate LayerNorm kernel.  Needs the ping-pong tiles, i.e. the big shapes (R >= 1024 rows, 128-column multiples).
+        ln_fold = os.environ.get("USDM_VB_LN_FOLD", "1") == "1" and use_split and wo_split <= 1 and H % 128 == 0 and I % 128 == 0 and R >= 2048
+        nt1 = H // 128
+        st1 = plan.hold(torch.zeros(R, nt1, 2, device=dev, dtype=torch.float32)) if ln_fold else None
+
         def layer(lp, cur, out16):
             ops.gemm(cur, lp["wqkv"], M=R, N=3 * H, Kc=H, bias=lp["bqkv"], plan=plan,
                      qkv=dict(S=S, Spad=Spad, H=nh, D=64, q=q, k=k, v=vt))
@@ -248,6 +262,17 @@ class Transformer(nn.Module):
                           q_strides=(nh * Spad * 64, Spad * 64, 64), k_strides=(nh * Spad * 64, Spad * 64, 64),
                           v_strides=(nh * 64 * Spad, 64 * Spad, Spad), o_strides=(S * H, H), scale=1.0,
                           kv_len=io["kv_len"], slopes=slopes, alibi_col0_zero=True, plan=plan)
+            if ln_fold:
+                # x1 = h + attn Wo + bo leaves as f32 (the un-normalised residual) and bf16 (FFN1's operand) with per-tile row sums;
+                # FFN1 applies LN1 to its accumulator, FFN2 applies it to the residual rows it adds
+                lnk = dict(stats=st1, nt=nt1, C=H, eps=1e-5)
+                ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=tmp32, out16=pc16, stats_out=st1, plan=plan)
+                ops.gemm(pc16, lp["w1g"], M=R, N=I, Kc=H, bias=lp["d1"], act=ACT_GELU, out16=f16, ln=dict(mode=1, c=lp["c1"], **lnk), plan=plan)
+                ops.gemm(f16, lp["w2"], M=R, N=H, Kc=I, bias=lp["b2"], residual=tmp32, ldr=H, out32=split2, split_k=nsp,
+                         c_split_stride=R * H, ln=dict(mode=2, gamma=lp["ln1"][0], beta=lp["ln1"][1], **lnk), plan=plan)
+                ops.norm(split2[0], *lp["ln2"], rows=R, C=H, res=split2[1], out32=h32, out16=out16, plan=plan,
+                         **(dict(res2=split2[2], n_res2=nsp - 2, res2_stride=R * H) if nsp > 2 else {}), **mk)
+                return
             if wo_split > 1:
                 ops.gemm(o16, lp["wo"], M=R, N=H, Kc=H, bias=lp["bo"], residual=h32, ldr=H, out32=split2, split_k=wo_split,
                          c_split_stride=R * H, plan=plan)
