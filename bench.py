@@ -256,7 +256,7 @@ def measure_gemv_roofline(llm):
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     try:  # PMC counters cannot be read from inside this process: use the committed rocprofv3 --pmc record of the same kernel
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_gemv_pmc.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_pmc.json")))
         if llm.tp_size == 1:
             traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
     except Exception:

@@ -80,22 +80,6 @@ __device__ unsigned long long g_gemm_trace[8192 * 8];
     }                                                                                                                       \
     if (tr_mode)                                                                                                            \
       for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;                       \
-    if constexpr (PP) {                                                                                                     \
-      if (a.ln_mode) {   /* folded LayerNorm: (rstd, rstd * mean) of this tile's rows from the producer's per-tile partial sums */ \
-        for (int i = tid; i < BM; i += NTH) {                                                                               \
-          const int m = m0 + i;                                                                                             \
-          float s1 = 0.f, s2 = 0.f;                                                                                         \
-          if (m < a.M) {                                                                                                    \
-            const float* sp = a.ln_stats + ((int64_t)bz * a.c_bstride + m) * a.ln_nt * 2;                                   \
-            for (int t = 0; t < a.ln_nt; ++t) { s1 += sp[2 * t]; s2 += sp[2 * t + 1]; }                                     \
-          }                                                                                                                 \
-          const float mean = s1 / (float)a.ln_C;                                                                            \
-          const float var = fmaxf(s2 / (float)a.ln_C - mean * mean, 0.f);                                                   \
-          const float rstd = rsqrtf(var + a.ln_eps);                                                                        \
-          rowst[2 * i] = rstd; rowst[2 * i + 1] = rstd * mean;                                                              \
-        }                                                                                                                   \
-      }                                                                                                                     \
-    }                                                                                                                       \
   } while (0)
 
 template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2, bool PP = false>
@@ -550,6 +534,25 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // before the K loop (bv/bu above) and residual rows are fetched a batch at a time ahead of their use: a load
   // inside the store loop costs a full memory latency per iteration (measured: 14 us of a 33 us 128x128 tile).
   TR(3);
+  if constexpr (PP) {
+    // folded LayerNorm: (rstd, rstd * mean) of this tile's rows from the producer's per-tile partial sums.  Requested HERE, after
+    // the K loop (in the prologue the loads' wait would sit in front of the first K-step): the latency runs under the accumulator
+    // dump below, and the barrier that follows the dump publishes rowst.
+    if (a.ln_mode) {
+      for (int i = tid; i < BM; i += NTH) {
+        const int m = m0 + i;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < a.M) {
+          const float2* sp = (const float2*)a.ln_stats + ((int64_t)bz * a.c_bstride + m) * a.ln_nt;
+          for (int t = 0; t < a.ln_nt; ++t) { const float2 v = sp[t]; s1 += v.x; s2 += v.y; }
+        }
+        const float mean = s1 / (float)a.ln_C;
+        const float var = fmaxf(s2 / (float)a.ln_C - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + a.ln_eps);
+        rowst[2 * i] = rstd; rowst[2 * i + 1] = rstd * mean;
+      }
+    }
+  }
   float* ct = (float*)smem;  // [BM][CST] f32, or [BN][CSTT] in transposed mode
   const void* resid = ksi == 0 ? a.residual : nullptr;                                     // split-K: split 0 owns bias + residual
   float* C32p = a.C32 ? (float*)a.C32 + (int64_t)ksi * a.c_split_stride : nullptr;

@@ -169,7 +169,7 @@ class Transformer(nn.Module):
             w1f = g(lay.feed_forward.intermediate_dense.weight)
             w1g = (w1f * g1[None, :]).to(bf).contiguous()
             fold = dict(w1g=w1g, c1=w1g.float().sum(1).contiguous(),
-                        d1=(g(lay.feed_forward.intermediate_dense.bias) + w1f @ be1).contiguous()) if bf == torch.bfloat16 else {}
+                        d1=(g(lay.feed_forward.intermediate_dense.bias) + (w1f * be1[None, :]).sum(1)).contiguous()) if bf == torch.bfloat16 else {}
             P["layers"].append(dict(
                 **fold,
                 wqkv=wqkv.to(bf).contiguous(), bqkv=bqkv.contiguous(),
