@@ -162,6 +162,7 @@ int usdm_cf_to_cl(const float* x, int32_t B, int32_t C, int32_t T, int32_t Cpad,
 typedef struct usdm_attn_args {
   int32_t mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_pos0, alibi_col0_zero;
   float scale;
+  int32_t head_order;   /* mode 0, speed only: 0 = library default, 1 = steepest ALiBi heads first and last in dispatch order, -1 = flattest first */
   const void* q; int64_t q_bs, q_hs, q_rs;
   const void* k; int64_t k_bs, k_hs, k_rs;
   const void* vt; int64_t v_bs, v_hs, v_ds;

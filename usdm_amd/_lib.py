@@ -76,7 +76,7 @@ class AttnArgs(C.Structure):
     _fields_ = [
         ("mode", C.c_int32), ("dh", C.c_int32), ("B", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
         ("Sq", C.c_int32), ("Skv", C.c_int32), ("Skv_alloc", C.c_int32), ("q_pos0", C.c_int32),
-        ("alibi_col0_zero", C.c_int32), ("scale", C.c_float),
+        ("alibi_col0_zero", C.c_int32), ("scale", C.c_float), ("head_order", C.c_int32),
         ("q", C.c_void_p), ("q_bs", C.c_int64), ("q_hs", C.c_int64), ("q_rs", C.c_int64),
         ("k", C.c_void_p), ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
         ("vt", C.c_void_p), ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_ds", C.c_int64),

@@ -52,7 +52,16 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
   // a bit more than one round of workgroups the short ones are the stragglers' partners, not the long ones.
   const int qb = blockIdx.x;
   const int lin = blockIdx.y + gridDim.y * blockIdx.z;
-  const int h = MODE == 0 ? (int)gridDim.y - 1 - lin / (int)gridDim.z : (int)blockIdx.y;
+  // MODE 0 head order (a.head_order; speed only): 0 = flattest first ... steepest last (round 2); 1 = the two steepest heads FIRST, the
+  // next two LAST, flat heads in between: a grid of a little more than one workgroup per CU (288 on 256) is dealt round-robin, so
+  // the CUs that receive a second workgroup hold the first and the last workgroups of the launch - with order 1 both are short
+  // (steep slope: most key tiles skipped), instead of a flat-slope one plus a steep one.
+  int h = (int)blockIdx.y;
+  if (MODE == 0) {
+    const int nh = (int)gridDim.y, p = lin / (int)gridDim.z;           // position of this (head, batch) pair in dispatch order
+    if (a.head_order == 0 || nh < 8) h = nh - 1 - p;
+    else h = p < 2 ? p : (p >= nh - 2 ? p - (nh - 2) + 2 : nh - 1 - (p - 2));
+  }
   const int b = MODE == 0 ? lin % (int)gridDim.z : (int)blockIdx.z;
   const int hk = h / (a.Hq / a.Hkv);
   const int q0 = qb * QB + wave * 32;
@@ -362,6 +371,11 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_ds % 8 == 0 && a.o_rs % 4 == 0, "usdm_attention: strides break 16-B alignment");
   USDM_CHECK_ARG(a.mode == 0 || a.mode == 1, "usdm_attention: mode");
   hipStream_t st = (hipStream_t)stream;
+  usdm_attn_args a2 = a;
+  if (a2.mode == 0 && a2.head_order == 0) {      // default order of the bidirectional (Voicebox) form; USDM_ATTN_ORDER=0 restores flattest-first
+    static const int ord = getenv("USDM_ATTN_ORDER") ? atoi(getenv("USDM_ATTN_ORDER")) : 1;
+    a2.head_order = ord;
+  } else if (a2.head_order < 0) a2.head_order = 0;
   // 2-wave workgroups (64 queries) when 4-wave ones would leave CUs with a single resident workgroup
   const bool small = getenv("USDM_ATTN_NW2") && (int64_t)cdiv(a.Sq, 128) * a.Hq * a.B < 1024;
   const int qb = small ? 64 : 128;
@@ -370,14 +384,14 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   static const int ks_env = getenv("USDM_ATTN_KS") ? atoi(getenv("USDM_ATTN_KS")) : -1;
   const bool ks2 = !small && a.dh == 64 && a.mode == 0 && (ks_env == 2);   // measured: no gain in situ (NFE 5.65 vs 5.58 ms), kept as an experiment switch
   if (ks2) {
-    hipLaunchKernelGGL((attn_kernel<64, 0, 4, 2>), grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL((attn_kernel<64, 0, 4, 2>), grid, dim3(512), 0, st, a2);
     USDM_LAUNCH_CHECK();
     return 0;
   }
 #define USDM_ATTN(DHV, MODEV)                                                                 \
   do {                                                                                         \
-    if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a);        \
-    else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a);              \
+    if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a2);        \
+    else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a2);              \
   } while (0)
   if (a.dh == 64 && a.mode == 0) USDM_ATTN(64, 0);
   else if (a.dh == 64) USDM_ATTN(64, 1);
