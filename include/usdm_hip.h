@@ -323,6 +323,10 @@ typedef struct usdm_sample_args {
   /* optional DEVICE copy of the knobs: when non-NULL it overrides temperature / top_k / top_p / seed above, so that one
    * captured decode graph serves every request (the host rewrites 24 bytes instead of re-capturing per seed). */
   const usdm_sample_params* dev_params;
+  /* batched decode (usdm_decode_state.batch > 1): sequence b reads logits + b * logits_bs, dev_params[b] (required), the state
+   * words [b] and writes h_out + b * Hd; its Philox counter is ITS step, so its tokens equal those of the single-sequence call
+   * (per-slot sampling inside a continuous batch: src/inference_vllm.py:109-123 passes one SamplingParams per request). */
+  int64_t logits_bs;
 } usdm_sample_args;
 int usdm_sample_final(const usdm_sample_args* args, const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd,
                       void* h_out_bf16, usdm_stream_t stream);

@@ -94,6 +94,50 @@ def test_continuous_batching_vs_oracle(dev):
     assert st["batched_steps"] < sum(max_new)                                                      # steps were shared between sequences
 
 
+def test_sampled_requests_inside_a_continuous_batch_equal_their_single_runs(dev):
+    """Per-slot sampling state in the batched decode (reference: src/inference_vllm.py:109-123 hands every request its own
+    SamplingParams; the demo's knobs: streamlit_demo.py:201-211): two SAMPLED requests (different temperature / top-k / top-p / seed)
+    and four greedy ones share one mask and are served together over the 4 slots.  A sampled request must return exactly the tokens
+    it returns when served alone on the single-sequence graph (same seed -> same Philox stream, same logits bit for bit); the greedy
+    ones must still equal the oracle."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    from usdm_amd.serving import LLM, SamplingParams
+    sd = MO.random_state_dict(SMALL, seed=49)
+    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256))
+    g = torch.Generator().manual_seed(6)
+
+    def ban(token_ids, logits):
+        logits[0:300] = float("-inf")
+        return logits
+    bad = [[i] for i in range(300)]
+    lens = (38, 22, 51, 30, 45, 27)
+    prompts = [torch.randint(0, 1000, (L,), generator=g).tolist() for L in lens]
+    sps = [SamplingParams(max_tokens=18, top_k=1, logits_processors=[ban]),
+           SamplingParams(max_tokens=24, temperature=1.3, top_p=0.9, top_k=50, seed=11, logits_processors=[ban]),
+           SamplingParams(max_tokens=9, top_k=1, logits_processors=[ban]),
+           SamplingParams(max_tokens=30, temperature=0.8, top_p=1.0, top_k=-1, seed=12345, logits_processors=[ban]),
+           SamplingParams(max_tokens=21, temperature=0.0, logits_processors=[ban]),
+           SamplingParams(max_tokens=14, top_k=1, logits_processors=[ban])]
+    outs = eng.generate(prompt_token_ids=prompts, sampling_params=sps)
+    st = dict(eng.stats)
+    assert st["batched_requests"] == 6 and st["sampled_in_batch"] == 2 and st["max_active"] == 4
+    for i in (1, 3):                                   # the sampled ones, alone
+        alone = eng.generate(prompt_token_ids=[prompts[i]], sampling_params=sps[i])[0].outputs[0].token_ids
+        got = outs[i].outputs[0].token_ids
+        assert got == alone, f"request {i}: sampled inside the batch {got} != alone {alone}"
+        assert len(got) == sps[i].max_tokens and all(t >= 300 for t in got)
+    a = eng.generate(prompt_token_ids=[prompts[1]], sampling_params=SamplingParams(max_tokens=24, temperature=1.3, top_p=0.9, top_k=50, seed=12,
+                                                                                  logits_processors=[ban]))[0].outputs[0].token_ids
+    assert a != outs[1].outputs[0].token_ids          # another seed, another stream
+    for i in (0, 2, 4, 5):                             # the greedy ones still equal the oracle (they rode the SAMPLING graph with top_k = 1)
+        p = torch.tensor(prompts[i])
+        ref, ref_logits = MO.greedy_generate(sd, SMALL, p, sps[i].max_tokens, bad_words_ids=bad, return_logits=True)
+        check_against_oracle(prompts[i] + outs[i].outputs[0].token_ids, ref, ref_logits, len(prompts[i]))
+    print("per-slot sampling in a continuous batch:", st)
+
+
 def test_batched_request_running_into_the_context_limit(dev):
     """the reference passes max_tokens = tokenizer.model_max_length, so a greedy sequence that never emits its stop id
     decodes up to the context limit.  In a continuous batch it must stop AT the limit (never append cache rows >= ctx_max, which

@@ -148,7 +148,7 @@ class SampleParams(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p), ("V", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
-        ("seed", C.c_uint64), ("probs_out", C.c_void_p), ("dev_params", C.c_void_p),
+        ("seed", C.c_uint64), ("probs_out", C.c_void_p), ("dev_params", C.c_void_p), ("logits_bs", C.c_int64),
     ]
 
 

@@ -57,8 +57,17 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(usdm_sample_args a, us
   __shared__ unsigned long long s_rem;
   __shared__ int s_tok;
   const int tid = threadIdx.x, V = a.V;
+  // batched decode (st.batch > 1): workgroup b = sequence b, with its OWN knobs (dev_params[b]), logits row, state words and
+  // Philox counter (its own step): a sequence sampled inside a continuous batch gets the tokens it would get alone
+  const int b = blockIdx.x;
+  a.logits += (int64_t)b * a.logits_bs;
+  if (a.probs_out) a.probs_out += (int64_t)b * a.logits_bs;
+  st.next_token += b; st.step += b; st.pos += b; st.out_tokens += (int64_t)b * st.max_out;
+  if (st.done) st.done += b;
+  h_out += (int64_t)b * Hd;
   if (st.done && *st.done) return;
   if (a.dev_params) {   // per-request knobs live in device memory: one captured graph for every request
+    a.dev_params += b;
     a.temperature = a.dev_params->temperature; a.top_k = a.dev_params->top_k; a.top_p = a.dev_params->top_p; a.seed = a.dev_params->seed;
     if (!(a.temperature > 0.f)) a.temperature = 1.0f;
     if (!(a.top_p > 0.f) || a.top_p > 1.0f) a.top_p = 1.0f;
@@ -169,7 +178,8 @@ __global__ __launch_bounds__(NT) void sample_final_kernel(usdm_sample_args a, us
   }
   const unsigned long long Zk = sscan[NT - 1];
   const int step = *st.step;
-  const double u = philox_uniform(a.seed, (unsigned)step);
+  // top_k == 1 is the reference's "greedy" (do_sample=True, top_k=1): among exact ties take the lowest id, as usdm_argmax_final does
+  const double u = a.top_k == 1 ? 0.0 : philox_uniform(a.seed, (unsigned)step);
   unsigned long long target = (unsigned long long)(u * (double)Zk);
   if (Zk > 0 && target >= Zk) target = Zk - 1;
   const unsigned long long excl = sscan[tid] - loc;
@@ -247,7 +257,9 @@ extern "C" int usdm_sample_final(const usdm_sample_args* pa, const usdm_decode_s
                  "usdm_sample_final: temperature > 0, 0 < top_p <= 1, top_k >= 0 (0 = off)");
   USDM_CHECK_ARG(st && st->next_token && st->out_tokens && st->step && st->pos, "usdm_sample_final: decode state");
   USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_sample_final: embedding output missing");
-  hipLaunchKernelGGL(sample_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, *pa, *st, (const bf16_t*)embed_table, Hd,
+  const int nb = st->batch > 1 ? st->batch : 1;
+  USDM_CHECK_ARG(nb == 1 || (pa->logits_bs >= pa->V && pa->dev_params), "usdm_sample_final: the batched form needs logits_bs >= V and dev_params[batch]");
+  hipLaunchKernelGGL(sample_final_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, *pa, *st, (const bf16_t*)embed_table, Hd,
                      (bf16_t*)h_out);
   USDM_LAUNCH_CHECK();
   return 0;

@@ -318,13 +318,15 @@ class USDMForCausalLM:
         (written per request by generate(): plans and graphs do not depend on temperature / top-k / top-p / seed)."""
         c = self.cfg
         sl = slot or self   # where the picked token, the decode state and the next input row live (self = the single sequence)
+        single = sl is self
         want_logits = self.keep_logits or bool(sampling)
         if want_logits and self.last_logits is None:
             self.last_logits = torch.zeros(self.v1 - self.v0, dtype=torch.float32, device=self.device)
+        # a batch slot samples from ITS logits row with ITS knobs (per-slot sampling inside a continuous batch)
+        logits = (self.last_logits if single else sl.logits) if want_logits else None
         ops.gemv(self.W["lm_head"], x, N=self.v1 - self.v0, K=c["hidden_size"], norm_w=self.W["norm"], eps=c["rms_norm_eps"],
-                 y32=self.last_logits if want_logits else None, ban=self.ban, part_val=sl.part_val_loc, part_idx=sl.part_idx_loc, idx_offset=self.v0,
+                 y32=logits, ban=self.ban, part_val=sl.part_val_loc, part_idx=sl.part_idx_loc, idx_offset=self.v0,
                  x_delta=x_delta, skip=skip, plan=plan)
-        single = sl is self
         st = ops.decode_state(sl.st_next, sl.st_out, sl.st_step, sl.st_pos, advance_pos=advance_pos,
                               done=self.st_done if single else None, eos=self.st_eos if single else None)
         if sampling:
@@ -334,8 +336,8 @@ class USDMForCausalLM:
                 segs.append(plan)
                 segs.append(lambda: self.logits_hook())
                 plan = ops.Plan()
-            ops.sample_final(self.last_logits, st, dev_params=self.sample_params,
-                             embed=self.W["embed"], h_out=self.h_dec, Hd=c["hidden_size"], plan=plan)
+            ops.sample_final(logits, st, dev_params=self.sample_params if single else sl.sample_params,
+                             embed=self.W["embed"], h_out=sl.h_dec, Hd=c["hidden_size"], plan=plan)
             plan.hold(st)
             segs.append(plan)
             return
@@ -570,7 +572,9 @@ class USDMForCausalLM:
         bb = dict(kc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
                   vc=torch.zeros(B, L, self.Hkv, self.ctx_max, d, dtype=bf, device=dev),
                   nxt=i32(B), step=i32(B), pos=i32(B), out=i32(B, self.max_out), h=torch.zeros(B, H, dtype=bf, device=dev),
-                  pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill=LRU(16), decode=None)
+                  pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill=LRU(16), decode=None,
+                  decode_sampled=None, logits=torch.zeros(B, self.v1 - self.v0, dtype=torch.float32, device=dev),
+                  sp=ops.sample_params_tensor(dev, B).view(B, -1))
         slots = []
         for b in range(B):
             sl = self._Slot()
@@ -579,13 +583,16 @@ class USDMForCausalLM:
             sl.h_dec = bb["h"][b]
             sl.part_val = sl.part_val_loc = bb["pv"][b]
             sl.part_idx = sl.part_idx_loc = bb["pi"][b]
+            sl.logits, sl.sample_params = bb["logits"][b], bb["sp"][b]
             slots.append(sl)
         bb["slots"] = slots
         self._batches[B] = bb
         return bb
 
-    def _build_decode_batch(self, B):
-        """One decode step of B sequences: weights streamed once (usdm_gemv_batch), attention / arg-max batched over items."""
+    def _build_decode_batch(self, B, sampling=False):
+        """One decode step of B sequences: weights streamed once (usdm_gemv_batch), attention / token pick batched over items.
+        sampling: the pick is usdm_sample_final's batched form - every slot draws with its OWN knobs (bb["sp"][b]: temperature,
+        top-k, top-p, seed) and its own Philox counter; a greedy slot carries top_k = 1."""
         c, dev, bf = self.cfg, self.device, torch.bfloat16
         H, d, L = c["hidden_size"], c["head_dim"], c["num_hidden_layers"]
         Hq, Hkv, I = self.Hq, self.Hkv, self.I
@@ -607,9 +614,13 @@ class USDMForCausalLM:
                            y16=act, plan=plan)
             ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
         ops.gemv_batch(self.W["lm_head"], h, nb=B, N=self.v1 - self.v0, K=H, x_bs=H, part_bs=self.nparts, norm_w=self.W["norm"],
-                       eps=c["rms_norm_eps"], ban=self.ban, part_val=bb["pv"], part_idx=bb["pi"], idx_offset=self.v0, plan=plan)
+                       eps=c["rms_norm_eps"], ban=self.ban, part_val=bb["pv"], part_idx=bb["pi"], idx_offset=self.v0,
+                       **(dict(y32=bb["logits"], y_bs=self.v1 - self.v0) if sampling else {}), plan=plan)
         st = ops.decode_state(bb["nxt"], bb["out"], bb["step"], bb["pos"], advance_pos=True, batch=B)
-        ops.argmax_final(bb["pv"], bb["pi"], self.nparts, st, embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
+        if sampling:
+            ops.sample_final(bb["logits"], st, dev_params=bb["sp"], embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
+        else:
+            ops.argmax_final(bb["pv"], bb["pi"], self.nparts, st, embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
         plan.hold(st)
         return plan
 

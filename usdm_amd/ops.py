@@ -308,12 +308,14 @@ def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, p
         _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 
 
-def sample_params_tensor(device):
-    """24-byte device block holding one usdm_sample_params (temperature, top_k, top_p, reserved, seed)."""
-    return torch.zeros(C.sizeof(_lib.SampleParams), dtype=torch.uint8, device=device)
+def sample_params_tensor(device, n=1):
+    """Device block holding n usdm_sample_params (24 bytes each: temperature, top_k, top_p, reserved, seed)."""
+    sz = C.sizeof(_lib.SampleParams)
+    return torch.zeros(sz if n == 1 else (n, sz), dtype=torch.uint8, device=device)
 
 
 def set_sample_params(t, temperature, top_k, top_p, seed):
+    """t: one 24-byte block (a row of sample_params_tensor(device, n) for slot b of a batch)"""
     p = _lib.SampleParams(float(temperature), int(top_k), float(top_p), 0, int(seed) & 0xFFFFFFFFFFFFFFFF)
     t.copy_(torch.frombuffer(bytearray(bytes(p)), dtype=torch.uint8))
 
@@ -321,10 +323,12 @@ def set_sample_params(t, temperature, top_k, top_p, seed):
 def sample_final(logits, st, *, temperature=1.0, top_k=0, top_p=1.0, seed=0, probs_out=None, embed=None, h_out=None, Hd=0,
                  dev_params=None, plan=None):
     """usdm_sample_final: temperature / top-k / top-p sampling of one token from ban-masked f32 logits.
-    dev_params (sample_params_tensor): the knobs are read from device memory instead (graph-replayable per request)."""
+    dev_params (sample_params_tensor): the knobs are read from device memory instead (graph-replayable per request).
+    Batched state (decode_state(batch=B)): logits [B][V], dev_params [B][24], h_out [B][Hd]; one workgroup per sequence."""
     _need_cuda(logits, probs_out, embed, h_out, dev_params)
     a = SampleArgs()
-    a.logits, a.V, a.temperature, a.top_k, a.top_p = _ptr(logits), logits.numel(), temperature, top_k, top_p
+    a.logits, a.V, a.temperature, a.top_k, a.top_p = _ptr(logits), logits.shape[-1], temperature, top_k, top_p
+    a.logits_bs = logits.stride(0) if logits.dim() == 2 else logits.numel()
     a.seed, a.probs_out, a.dev_params = seed, _ptr(probs_out), _ptr(dev_params)
     _go(plan, "usdm_sample_final", lib.usdm_sample_final, C_.byref(a), C_.byref(st), _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 

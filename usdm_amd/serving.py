@@ -7,12 +7,14 @@ How requests are executed
   * logits processors that are STATIC masks (the reference's three `bad_word_processor_*` only write -inf into fixed id ranges)
     are recognised by probing and turned into the device-side ban mask: banned lm_head rows are not even streamed, and the
     decode step stays one hipGraph;
-  * several greedy requests (top_k = 1 / temperature = 0, what the reference passes) that share a mask are served by CONTINUOUS
-    BATCHING over the 4 sequence slots of the batched decode (usdm_gemv_batch: the weights are streamed once per step for all
-    slots): a finished sequence's slot is refilled from the queue at the next scheduling point (every 8 steps) while the other
-    slots keep decoding;
-  * sampled requests and single requests use the single-sequence graph (usdm_sample_final: temperature / top-k / top-p on the
-    device, `seed` per request);
+  * several requests that share a mask - greedy (top_k = 1 / temperature = 0, what the reference passes) AND sampled - are served by
+    CONTINUOUS BATCHING over the 4 sequence slots of the batched decode (usdm_gemv_batch: the weights are streamed once per step
+    for all slots): a finished sequence's slot is refilled from the queue at the next scheduling point (every 8 steps) while
+    the other slots keep decoding.  Sampling state is PER SLOT (usdm_sample_final's batched form: every slot has its own
+    temperature / top-k / top-p / seed block on the device and its own Philox counter), so a request sampled inside a batch
+    returns exactly the tokens it returns alone; a greedy request in a sampled batch carries top_k = 1;
+  * a single request uses the single-sequence graph (usdm_sample_final: temperature / top-k / top-p on the device, `seed` per
+    request);
   * processors that really depend on the token history run as Python between the lm_head launch and the pick of every step
     (eager launches: correct, not fast).
 """
@@ -156,15 +158,18 @@ class LLM:
             if eos is not None and not sp.ignore_eos:
                 stops.add(int(eos))
             room = self.llm.ctx_max - len(ids)
-            reqs.append(dict(i=i, rid=str(self._next_id + i), text=text, ids=ids, sp=sp, mask=mask, stops=stops,
+            seed = sp.seed
+            if not sp.greedy and seed is None:      # as generate(): a fresh stream per call, reproducible under torch.manual_seed
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            reqs.append(dict(i=i, rid=str(self._next_id + i), text=text, ids=ids, sp=sp, mask=mask, stops=stops, seed=seed,
                              max_new=max(0, min(sp.max_tokens, room, self.llm.max_out))))
         self._next_id += n
         self.stats["requests"] += n
         done = {}
-        # continuous batching: greedy requests with the same static mask, at least two of them
+        # continuous batching: requests with the same static mask (greedy and sampled alike), at least two of them
         groups = {}
         for r in reqs:
-            if r["mask"] is not None and r["sp"].greedy and r["max_new"] > 0 and not self.llm.tp_path:
+            if r["mask"] is not None and r["max_new"] > 0 and not self.llm.tp_path:
                 groups.setdefault(bytes(r["mask"].cpu().numpy().tobytes()), []).append(r)
         for grp in groups.values():
             if len(grp) >= 2:
@@ -184,7 +189,7 @@ class LLM:
         kw = dict(input_ids=ids, max_new_tokens=r["max_new"], eos_token_id=sorted(r["stops"]) or None, min_new_tokens=sp.min_tokens)
         sampled = not sp.greedy
         if sampled:
-            kw.update(do_sample=True, temperature=sp.temperature, top_p=sp.top_p, top_k=(sp.top_k if sp.top_k > 0 else None), seed=sp.seed)
+            kw.update(do_sample=True, temperature=sp.temperature, top_p=sp.top_p, top_k=(sp.top_k if sp.top_k > 0 else None), seed=r["seed"])
         if r["mask"] is not None:
             out = llm.generate(ban_mask=r["mask"], **kw)
         else:       # history-dependent processors: Python between the lm_head launch and the pick of every step
@@ -209,9 +214,16 @@ class LLM:
     # ------------------------------------------------------------------ continuous batching over the 4 decode slots
     def _run_batched(self, grp):
         llm = self.llm
+        from . import ops
         bb = llm._batch_buffers(MAX_SLOTS)
-        if bb["decode"] is None:
-            bb["decode"] = GraphedPlan(llm._build_decode_batch(MAX_SLOTS))
+        sampled = any(not r["sp"].greedy for r in grp)       # one sampled request -> the whole group runs on the sampling graph
+        key = "decode_sampled" if sampled else "decode"
+        if bb[key] is None:
+            bb[key] = GraphedPlan(llm._build_decode_batch(MAX_SLOTS, sampling=sampled))
+        decode = bb[key]
+        self.stats["sampled_in_batch"] = self.stats.get("sampled_in_batch", 0) + sum(not r["sp"].greedy for r in grp)
+        for b in range(MAX_SLOTS):                               # idle slots: harmless greedy knobs
+            ops.set_sample_params(bb["sp"][b], 1.0, 1, 1.0, 0)
         llm.ban.copy_(grp[0]["mask"][llm.v0:llm.v1])
         queue, slots, results = deque(grp), [None] * MAX_SLOTS, []
         self.stats["batched_requests"] += len(grp)
@@ -222,7 +234,13 @@ class LLM:
                     L = len(r["ids"])
                     bb["step"][b] = 0
                     bb["pos"][b] = L
-                    segs, io = bb["prefill"].get_or_build((L, b), lambda: llm._build_prefill(L, None, slot=bb["slots"][b]))
+                    sp = r["sp"]
+                    if sp.greedy:
+                        ops.set_sample_params(bb["sp"][b], 1.0, 1, 1.0, 0)
+                    else:
+                        ops.set_sample_params(bb["sp"][b], sp.temperature, max(sp.top_k, 0), sp.top_p, r["seed"])
+                    # the first token is picked by the prefill: sampled too when the group runs on the sampling graph
+                    segs, io = bb["prefill"].get_or_build((L, b, sampled), lambda: llm._build_prefill(L, True if sampled else None, slot=bb["slots"][b]))
                     io["ids"].copy_(torch.tensor(r["ids"], dtype=torch.long))
                     llm._run_segs(segs)                               # (+ first token)
                     slots[b] = dict(r=r, produced=1)
@@ -256,7 +274,7 @@ class LLM:
             # next slot's cache rows.  usdm_attn_decode additionally refuses positions >= ctx_max.
             n = min(CHUNK, min(slots[b]["r"]["max_new"] - slots[b]["produced"] for b in live))
             for _ in range(n):
-                bb["decode"].run()
+                decode.run()
             self.stats["batched_steps"] += n
             for b in live:
                 slots[b]["produced"] = min(slots[b]["produced"] + n, slots[b]["r"]["max_new"])
