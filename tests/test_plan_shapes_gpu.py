@@ -1,0 +1,265 @@
+"""GPU: EVERY usdm_gemm launch that the real launch plans emit - Voicebox estimator (full width, CFG batch 2, S = 1118), Mistral-7B
+prefill (7B widths), BigVGAN (full 1536-channel generator) and the XLS-R tokenizer (1B widths) - checked one by one against an
+independent emulation of the tap-GEMM contract of include/usdm_hip.h (round-2 review, weak 3: the shape list of the kernel unit tests
+must come from the plans, not from hand-picked sizes; a half K-step tail at K = 1440 was once missed that way).
+
+How: ops.gemm is wrapped while a plan is built, so every call's tensors and keyword arguments are captured; calls are de-duplicated
+by their full signature (sizes, strides, taps, epilogue, tile-relevant fields); each unique call is then launched ALONE on fresh
+random operands (its real weights kept) and compared with `emulate`, a float64 torch restatement of the contract that walks the
+same strides / taps / groups / batches / epilogues (bias, GELU, SwiGLU, tanh, residual, transposed, head-split QKV, split-K,
+folded-LayerNorm producer and consumers).  Depth is reduced to the layers that produce distinct signatures."""
+import contextlib
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ capture
+@contextlib.contextmanager
+def capture_gemms(store):
+    from usdm_amd import ops
+    real = ops.gemm
+
+    def spy(A, W, **kw):
+        store.append((A, W, dict(kw)))
+        return real(A, W, **kw)
+    ops.gemm = spy
+    try:
+        yield
+    finally:
+        ops.gemm = real
+
+
+def signature(A, W, kw):
+    t = lambda x: None if x is None else (str(x.dtype), )
+    skip = {"plan", "bias", "residual", "out32", "out16", "qkv", "stats_out", "ln"}
+    sig = [str(A.dtype)] + sorted((k, v) for k, v in kw.items() if k not in skip)
+    sig += [("bias", kw.get("bias") is not None), ("res", t(kw.get("residual"))), ("o32", kw.get("out32") is not None),
+            ("o16", kw.get("out16") is not None), ("stats", kw.get("stats_out") is not None)]
+    if kw.get("qkv"):
+        q = kw["qkv"]
+        sig.append(("qkv", q["S"], q["Spad"], q["H"], q["D"]))
+    if kw.get("ln"):
+        sig.append(("ln", kw["ln"]["mode"], kw["ln"]["nt"], kw["ln"]["C"]))
+    return tuple(map(str, sig))
+
+
+# ------------------------------------------------------------------------------------------------ emulator (float64, CPU)
+def _flat(t):
+    """the whole storage behind a (possibly offset / strided) view, as a flat f64 tensor + the view's element offset"""
+    base = torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage())
+    return base, t.storage_offset()
+
+
+def emulate(A, W, kw):
+    from usdm_amd._lib import ACT_GELU, ACT_SWIGLU, ACT_TANH
+    M, N, Kc = kw["M"], kw["N"], kw["Kc"]
+    taps = kw.get("taps", 1)
+    lda = kw["lda"] if kw.get("lda") is not None else A.stride(-2)
+    ldw = kw["ldw"] if kw.get("ldw") is not None else taps * Kc
+    rowsA = kw["rowsA"] if kw.get("rowsA") is not None else M
+    mul, off, step, tstr = kw.get("a_row_mul", 1), kw.get("a_row_off", 0), kw.get("a_row_step", 0), kw.get("a_tap_stride", 0)
+    G, Bt = kw.get("groups", 1), kw.get("batch", 1)
+    ags, wgs, abs_, gcol, cbs = kw.get("a_gstride", 0), kw.get("w_gstride", 0), kw.get("a_bstride", 0), kw.get("c_gcol", 0), kw.get("c_bstride", 0)
+    alpha, act = kw.get("alpha", 1.0), kw.get("act", 0)
+    Af, ao = _flat(A)
+    Wf, wo = _flat(W)
+    Af, Wf = Af.double().cpu(), Wf.double().cpu()
+    bias = kw["bias"].double().cpu() if kw.get("bias") is not None else None
+    ln = kw.get("ln")
+    if ln:
+        st = ln["stats"].double().cpu()
+        mean = st[..., 0].sum(-1) / ln["C"]
+        rstd = ((st[..., 1].sum(-1) / ln["C"] - mean * mean).clamp_min(0) + ln.get("eps", 1e-5)).rsqrt()
+    out = {}          # (b, g) -> f64 [M, Nout]
+    m = torch.arange(M)
+    for b in range(Bt):
+        for g in range(G):
+            acc = torch.zeros(M, N, dtype=torch.float64)
+            for t in range(taps):
+                rows = m * mul + off + t * step
+                ok = (rows >= 0) & (rows < rowsA)
+                idx = ao + ags * g + abs_ * b + rows.clamp(0, rowsA - 1)[:, None] * lda + t * tstr + torch.arange(Kc)[None, :]
+                X = Af[idx] * ok[:, None]
+                widx = wo + wgs * g + torch.arange(N)[:, None] * ldw + t * Kc + torch.arange(Kc)[None, :]
+                acc += X @ Wf[widx].T
+            if ln and ln["mode"] == 1:          # LN(x) W0^T + b from un-normalised rows and gamma-folded weights
+                c = ln["c"].double().cpu()
+                r, mu = rstd[b * cbs + m if cbs else m], mean[b * cbs + m if cbs else m]
+                v = r[:, None] * acc - (r * mu)[:, None] * c[None, gcol * g:gcol * g + N]
+            else:
+                v = alpha * acc
+            if bias is not None:
+                v = v + bias[None, gcol * g:gcol * g + N]
+            if kw.get("round_bf16"):
+                v = v.to(torch.bfloat16).double()
+            if act == ACT_SWIGLU:
+                vv = v.view(M, N // 32, 2, 16)
+                gt, up = vv[:, :, 0], vv[:, :, 1]
+                if kw.get("round_bf16"):
+                    v = ((gt * torch.sigmoid(gt)).to(torch.bfloat16).double() * up).to(torch.bfloat16).double().reshape(M, N // 2)
+                else:
+                    v = (gt * torch.sigmoid(gt) * up).reshape(M, N // 2)
+            elif act == ACT_GELU:
+                v = torch.nn.functional.gelu(v)
+            elif act == ACT_TANH:
+                v = torch.tanh(v)
+            out[(b, g)] = v
+    return out, (mean, rstd) if ln else None
+
+
+def _row_out(kw, b, M):
+    return (b * kw.get("c_bstride", 0) + torch.arange(M)) * kw.get("c_row_mul", 1) + kw.get("c_row_off", 0)
+
+
+def check_call(dev, A, W, kw, name):
+    """launch the captured call alone on fresh random operands and compare every output with the emulator"""
+    from usdm_amd import ops
+    from usdm_amd._lib import ACT_SWIGLU
+    g = torch.Generator().manual_seed(hash(name) % (2 ** 31))
+    kw = dict(kw)
+    kw.pop("plan", None)
+    bf = A.dtype == torch.bfloat16
+    # fresh activations in the A storage (weights stay); residual / LN statistics likewise
+    Af, _ = _flat(A)
+    Af.copy_((torch.randn(Af.numel(), generator=g) * 0.5).to(Af.dtype))
+    M, N = kw["M"], kw["N"]
+    if kw.get("residual") is not None:
+        r = kw["residual"]
+        rf, _ = _flat(r)
+        rf.copy_((torch.randn(rf.numel(), generator=g)).to(rf.dtype))
+    ln = kw.get("ln")
+    if ln:
+        ln = dict(ln)
+        rows = ln["stats"].shape[0]
+        x = torch.randn(rows, ln["nt"], ln["C"] // ln["nt"], generator=g) * 1.5 + 0.3
+        ln["stats"] = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).float().to(dev).contiguous()
+        kw["ln"] = ln
+    outs = {k: kw[k] for k in ("out32", "out16") if kw.get(k) is not None}
+    inputs = {x.untyped_storage().data_ptr() for x in (A, W, kw.get("residual")) if x is not None}
+    for t in outs.values():
+        if t.untyped_storage().data_ptr() not in inputs:      # (the LLM's o_proj / down_proj write the residual stream in place)
+            tf, _ = _flat(t)
+            tf.zero_()
+    res_saved = None
+    if kw.get("residual") is not None:
+        rf0, _ = _flat(kw["residual"])
+        res_saved = rf0.double().cpu()
+    ref, lnst = emulate(A, W, kw)                               # (before the launch: an in-place output may overwrite A's storage)
+    ops.gemm(A, W, **kw)
+    torch.cuda.synchronize()
+    G, Bt, gcol = kw.get("groups", 1), kw.get("batch", 1), kw.get("c_gcol", 0)
+    Nout = N // 2 if kw.get("act", 0) == ACT_SWIGLU else N
+    ldc = kw["ldc"] if kw.get("ldc") is not None else N
+    tol = 3e-2 if bf else 2e-4        # bf16 outputs / f32 MFMA chains of up to 16 896 products against float64
+    scale = max(v.abs().max().item() for v in ref.values()) + 1e-9
+    worst = 0.0
+    res = kw.get("residual")
+    for (b, gi), v in ref.items():
+        rows = _row_out(kw, b, M)
+        cols = (gcol * gi if kw.get("act", 0) != ACT_SWIGLU else (gcol * gi) // 2) + torch.arange(Nout)
+        if res is not None:
+            _, ro = _flat(res)
+            rr = res_saved[ro + rows[:, None] * kw["ldr"] + cols[None, :]]
+            if ln and ln["mode"] == 2:
+                mean, rstd = lnst
+                gam, bet = ln["gamma"].double().cpu()[cols], ln["beta"].double().cpu()[cols]
+                rr = (rr - mean[rows][:, None]) * rstd[rows][:, None] * gam[None] + bet[None]
+            v = v + rr
+            if kw.get("round_bf16"):
+                v = v.to(torch.bfloat16).double()
+        sk = kw.get("split_k", 0)
+        if kw.get("qkv"):
+            q = kw["qkv"]
+            S, Sp, H, D = q["S"], q["Spad"], q["H"], q["D"]
+            bb, ss = torch.arange(M) // S, torch.arange(M) % S
+            for part, buf in enumerate((q["q"], q["k"])):
+                got = buf.double().cpu()[bb, :, ss, :].reshape(M, H * D)          # [B][H][Spad][D]
+                worst = max(worst, (got - v[:, part * H * D:(part + 1) * H * D]).abs().max().item())
+            got = q["v"].double().cpu()[bb, :, :, ss].reshape(M, H * D)              # V^T [B][H][D][Spad]
+            worst = max(worst, (got - v[:, 2 * H * D:]).abs().max().item())
+            continue
+        for key, t in outs.items():
+            tf, to = _flat(t)
+            tf = tf.double().cpu()
+            if sk and sk > 1:
+                got = sum(tf[to + s * kw["c_split_stride"] + rows[:, None] * ldc + cols[None, :]] for s in range(sk))
+            elif kw.get("transpose_out"):
+                got = tf[to + cols[None, :] * ldc + rows[:, None]]
+            else:
+                got = tf[to + rows[:, None] * ldc + cols[None, :]]
+            worst = max(worst, (got - v).abs().max().item())
+        if kw.get("stats_out") is not None:
+            sto = kw["stats_out"].double().cpu()
+            vs = v.view(M, N // 128, 128)
+            worst = max(worst, (sto[rows][:, :, 0] - vs.sum(-1)).abs().max().item() / 128)
+    assert worst <= tol * scale, f"{name}: max |err| {worst:.3e} vs scale {scale:.3e} (tol {tol})  kw={ {k: v for k, v in kw.items() if not torch.is_tensor(v) and k not in ('qkv', 'ln')} }"
+    return worst / scale
+
+
+def run_unique(dev, store, label):
+    seen, n = {}, 0
+    for A, W, kw in store:
+        sig = signature(A, W, kw)
+        if sig in seen:
+            continue
+        seen[sig] = True
+        n += 1
+        check_call(dev, A, W, kw, f"{label} #{n} M{kw['M']} N{kw['N']} K{kw['Kc']}x{kw.get('taps', 1)}")
+    return n, len(store)
+
+
+# ------------------------------------------------------------------------------------------------ the plans
+def test_every_gemm_of_the_voicebox_plan(dev):
+    from usdm_amd import synth
+    cfg = dict(synth.VOICEBOX_CFG, num_hidden_layers=4)           # layers 0-1 push, 2-3 pop: every distinct signature of the 24-layer plan
+    vb = synth.make_voicebox(dev, cfg)
+    store = []
+    with capture_gemms(store):
+        vb.estimator.build_plan(1, 1117, 2, True, dev, ragged=False)
+    n, tot = run_unique(dev, store, "voicebox bf16")
+    assert n >= 8, (n, tot)
+    store32 = []
+    vb.estimator.set_compute_dtype(torch.float32)
+    with capture_gemms(store32):
+        vb.estimator.build_plan(1, 1117, 2, True, dev, ragged=False)
+    n32, tot32 = run_unique(dev, store32, "voicebox f32")
+    print(f"voicebox plan: {n} distinct GEMM signatures of {tot} launches (bf16 plan), {n32} of {tot32} (exact-f32 plan), all equal to the emulation")
+
+
+def test_every_gemm_of_the_llm_prefill_plan(dev):
+    from usdm_amd import synth
+    from usdm_amd.llm import MISTRAL_7B_USDM
+    cfg = dict(MISTRAL_7B_USDM, num_hidden_layers=1)
+    llm = synth.make_llm(dev, cfg, ctx_max=1024)
+    seen = 0
+    for S, past in ((548, 0), (38, 548), (619, 0)):                 # the bench's three prompts: full prefill, prefix-reuse tail, long prompt
+        store = []
+        with capture_gemms(store):
+            llm._build_prefill(S, None, past=past)
+        n, tot = run_unique(dev, store, f"llm prefill S{S}")
+        seen += n
+    print(f"LLM prefill plans: {seen} distinct GEMM signatures, all equal to the emulation")
+    assert seen >= 9
+
+
+def test_every_gemm_of_the_bigvgan_and_tokenizer_plans(dev):
+    from usdm_amd import synth
+    from usdm_amd.plancache import Arena
+    voc = synth.make_bigvgan(dev)
+    voc._packed = voc._pack(dev)
+    store = []
+    with capture_gemms(store):
+        voc._build_plan(37, dev, Arena(dev))                       # every conv / transposed-conv phase of the six stages, ragged length
+    n, tot = run_unique(dev, store, "bigvgan f32")
+    ue = synth.make_unit_extractor(dev, n_layers=2)
+    store2 = []
+    with capture_gemms(store2):
+        ue._build(16000, 1, Arena(dev))
+    n2, tot2 = run_unique(dev, store2, "xls-r f32")
+    print(f"BigVGAN plan: {n} distinct GEMM signatures of {tot} launches; XLS-R plan: {n2} of {tot2}; all equal to the emulation")
+    assert n >= 20 and n2 >= 10
