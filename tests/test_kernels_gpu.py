@@ -107,6 +107,19 @@ def _attn_ref(q, k, v, mode, slopes=None, kv_len=None, scale=1.0, q_pos0=0):
 @pytest.mark.parametrize("mode,dh,B,H,Hkv,Sq", [(0, 64, 2, 4, 4, 300), (0, 64, 1, 16, 16, 1118), (1, 128, 1, 8, 2, 200),
                                                 (1, 128, 1, 4, 1, 577), (0, 128, 1, 2, 2, 130), (1, 64, 2, 2, 2, 64)])
 def test_attention(dev, mode, dh, B, H, Hkv, Sq):
+    _attention_case(dev, mode, dh, B, H, Hkv, Sq)
+
+
+@pytest.mark.parametrize("v16", ["0", "1"])
+@pytest.mark.parametrize("B,H,Sq", [(2, 4, 300), (1, 16, 1118), (1, 8, 17), (3, 8, 129), (2, 16, 64)])
+def test_attention_voicebox_form_both_kernels(dev, monkeypatch, v16, B, H, Sq):
+    """The bidirectional ALiBi form (d = 64, MHA) through the 16-query-wave kernel (default) and the 32-query-wave one
+    (USDM_ATTN_V16=0): ragged kv_len, query counts that end inside a wave / inside a workgroup, fewer than 8 heads."""
+    monkeypatch.setenv("USDM_ATTN_V16", v16)
+    _attention_case(dev, 0, 64, B, H, H, Sq)
+
+
+def _attention_case(dev, mode, dh, B, H, Hkv, Sq):
     from usdm_amd import ops
     Spad = (Sq + 63) // 64 * 64
     bf = torch.bfloat16
@@ -114,7 +127,7 @@ def test_attention(dev, mode, dh, B, H, Hkv, Sq):
     k = _r((B, Hkv, Sq, dh), 2, 0.5).to(bf)
     v = _r((B, Hkv, Sq, dh), 3, 1.0).to(bf)
     slopes = torch.tensor([2.0 ** (-(i + 1) / 2) for i in range(H)])
-    kv_len = torch.tensor([Sq, max(1, Sq - 37)][:B], dtype=torch.int32)
+    kv_len = torch.tensor([Sq, max(1, Sq - 37), 1][:B], dtype=torch.int32)
     scale = 1.0 if mode == 0 else dh ** -0.5
     qd = torch.zeros(B, H, Spad, dh, dtype=bf, device=dev); qd[:, :, :Sq] = q.to(dev)
     kd = torch.zeros(B, Hkv, Spad, dh, dtype=bf, device=dev); kd[:, :, :Sq] = k.to(dev)

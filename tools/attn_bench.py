@@ -16,9 +16,12 @@ ks = [torch.randn(Bx, nh, Spad, 64, device=dev).to(bf) * 0.5 for _ in range(L)]
 vts = [torch.randn(Bx, nh, 64, Spad, device=dev).to(bf) for _ in range(L)]
 H = nh * 64
 slopes = torch.tensor([2 ** (-(i + 1) / 2) for i in range(nh)], device=dev)
+if os.environ.get("AB_FLAT"):
+    slopes = torch.full((nh,), float(os.environ["AB_FLAT"]), device=dev)     # no far-tile skipping: every key tile is computed
 kvl = torch.tensor([S] * Bx, dtype=torch.int32, device=dev)
 outs = {}
-for v2 in ("-",):
+for v2 in os.environ.get("AB_VARIANTS", "0,1").split(","):
+    os.environ["USDM_ATTN_V16"] = v2
     o = torch.zeros(Bx * S, H, device=dev, dtype=bf)
     plan = ops.Plan()
     for i in range(L):
@@ -36,4 +39,9 @@ for v2 in ("-",):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (10 * L)
     fl = 4 * Bx * nh * S * S * 64
-    print(f"B={Bx} H={nh} S={S}: {us:6.2f} us per launch  ({fl / us / 1e6:5.0f} TF/s)", flush=True)
+    outs[v2] = o.float().clone()
+    print(f"USDM_ATTN_V16={v2} B={Bx} H={nh} S={S}: {us:6.2f} us per launch  ({fl / us / 1e6:5.0f} TF/s)", flush=True)
+ks_ = list(outs)
+for k in ks_[1:]:
+    d = (outs[k] - outs[ks_[0]]).abs().max().item()
+    print(f"max |out[{k}] - out[{ks_[0]}]| = {d:.3e} (max |out| {outs[ks_[0]].abs().max().item():.3f})")

@@ -160,6 +160,12 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
   const int nit = (ntiles + KS - 1) / KS;                  // barrier count is the same for every group
   const int myn = ntiles > grp ? (ntiles - grp + KS - 1) / KS : 0;
   if (myn > 0) { load_tile(grp); store_tile(0); }
+  // The Q fragments are consumed here on EVERY path into the loop.  Without this the wait-count pass merges the (myn == 0) path,
+  // on which the Q loads are still in flight, into the loop header and puts s_waitcnt vmcnt(0) in front of the loop's first MFMAs:
+  // every key tile then waits for the prefetch loads issued at the end of the previous tile, i.e. a full L2 / fabric latency per
+  // tile with nothing to hide it (found in round 3 from the ISA; profiles/r03_vb_ablation.txt item 7).
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, qf[s])));
   if (myn > 1) load_tile(grp + KS);
   __syncthreads();
   ATR_ADD(0, tph);
@@ -354,6 +360,261 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
       }
   }
 }
+
+// ---- 16-query waves (Voicebox: bidirectional + ALiBi, d = 64) -------------------------------------------------------------------
+// The 32-query kernel above keeps ONE wave per SIMD when the grid is about one workgroup per CU (2 x 16 heads x 9 query blocks =
+// 288 workgroups on 256 CUs), and its loop is bound by the instruction stream of that single wave (profiles/r03_vb_ablation.txt
+// item 2: ~8.5 cycles per instruction with nothing to switch to).  Here the same 128-query workgroup is EIGHT waves of 16 queries:
+// S^T tiles are v_mfma_f32_16x16x32_bf16, two waves share a SIMD, and one wave's exponentials run under the other's MFMAs.
+//   S^T[key][query]: A = K rows (lane l: row l&15, k = 8 (l>>4) + j), B = Q^T (lane: query l&15, same k), accumulator lane
+//   (query l&15, rows 4 (l>>4) + i).  The P.V step needs, per lane, EIGHT consecutive keys of a 32-key block as its B operand
+//   (k = 8 (l>>4) + j), but an accumulator holds four rows per 16-row tile: the two S tiles (t = 0, 1) of a 32-key block therefore
+//   read K rows PERMUTED, tile t row rho <- key 8 (rho>>2) + 4 t + (rho&3), so that lane group g ends up with keys 8g .. 8g+7 in
+//   (tile 0 regs 0..3, tile 1 regs 0..3): P^T goes from the accumulators to the MFMA B operand with no cross-lane traffic.
+//   O^T[d][query] += V^T[d][key] . P^T: A = V^T rows as stored (lane: d = 16 dt + (l&15), keys 8 (l>>4) + j of the block).
+// LDS image: rows of 128 B (K row = 64 d, V^T row = 64 keys), 16-B piece c of row r at c ^ f(r), f(r) = (r & 2) | ((r >> 1) & 4):
+// conflict-free for both b128 read patterns above (checked exhaustively against the ds_read_b128 lane groups).
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__device__ __forceinline__ float quad_max16(float v) {    // max over the 4 lanes l, l^16, l^32, l^48 (v_permlane swaps, no LDS)
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_sum16(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// (A half-iteration skew of waves 4..7 against 0..3 - their barrier between softmax and P.V, four-stage ring - was measured too:
+// within 1 % at S = 1118, +4 % only at S = 4096; not kept.  profiles/r03_vb_ablation.txt item 7.)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn16_kernel(const usdm_attn_args a) {
+  constexpr int NT = NW * 64, QB = NW * 16, STAGE = 2 * KT * 128, NP = 512 / NT;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q16 = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x;
+  const int lin = blockIdx.y + gridDim.y * blockIdx.z;
+  const int nh = (int)gridDim.y, p = lin / (int)gridDim.z;
+  int h;
+  if (a.head_order == 0 || nh < 8) h = nh - 1 - p;
+  else h = p < 2 ? p : (p >= nh - 2 ? p - (nh - 2) + 2 : nh - 1 - (p - 2));
+  const int b = lin % (int)gridDim.z;
+  const int q0 = qb * QB + wave * 16;
+  const int kv_len = a.kv_len ? a.kv_len[b] : a.Skv;
+  const bf16_t* Q = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
+  const bf16_t* K = (const bf16_t*)a.k + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
+  const bf16_t* V = (const bf16_t*)a.vt + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
+
+  bf16x8 qf[2];
+  {
+    int qr = q0 + q16;
+    if (qr > a.Sq - 1) qr = a.Sq - 1;
+    const bf16_t* qp = Q + (int64_t)qr * a.q_rs + 8 * g;
+    qf[0] = __builtin_bit_cast(bf16x8, *(const u32x4*)qp);
+    qf[1] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + 32));
+  }
+  f32x4v oacc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) oacc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+  const int qpos = a.q_pos0 + q0 + q16;
+  const float slope2 = (a.slopes ? a.slopes[h] : 0.f) * 1.4426950408889634f;
+  const float sc = a.scale * 1.4426950408889634f;
+  // ALiBi term of register pair (i, i+1) of S tile (b32, t): slope2 * (key offset inside the 64-key tile, lane part 8g aside)
+  f32x2 cb[2][2][2];
+#pragma unroll
+  for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const float c = (float)(32 * b32 + 4 * t + i);
+        cb[b32][t][i >> 1] = f32x2{slope2 * c, slope2 * (c + 1.0f)};
+      }
+  const int ntiles = (kv_len + KT - 1) / KT;
+
+  // loaders: one 16-B piece of the K tile and one of the V^T tile per thread
+  const int lrow = tid >> 3, lc = tid & 7;                   // piece i of this thread: row lrow + (NT/8) i, 16-B column lc
+  const bf16_t* kp = K + (int64_t)lrow * a.k_rs + lc * 8;
+  const bf16_t* vp = V + (int64_t)lrow * a.v_ds + lc * 8;
+  u32x4 rk[NP], rv[NP];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      rk[i] = *(const u32x4*)(kp + ((int64_t)kt * KT + (NT / 8) * i) * a.k_rs);
+      rv[i] = *(const u32x4*)(vp + (int64_t)(NT / 8) * i * a.v_ds + kt * KT);
+    }
+  };
+  auto store_tile = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = lrow + (NT / 8) * i;
+      const int lofs = r * 128 + ((lc ^ ((r & 2) | ((r >> 1) & 4))) << 4);
+      *(u32x4*)(smem + stage * STAGE + lofs) = rk[i];
+      *(u32x4*)(smem + stage * STAGE + KT * 128 + lofs) = rv[i];
+    }
+  };
+  // fragment addresses of this lane (bytes inside a stage): K row of S tile (b32, t) and V^T row of d-tile dt
+  int kofs[2][2][2], vofs[4][2];
+#pragma unroll
+  for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 32 * b32 + 8 * (q16 >> 2) + 4 * t + (q16 & 3);
+      const int f = (row & 2) | ((row >> 1) & 4);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) kofs[b32][t][s] = row * 128 + (((4 * s + g) ^ f) << 4);
+    }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = 16 * dt + q16;
+    const int f = (d & 2) | ((d >> 1) & 4);
+#pragma unroll
+    for (int b32 = 0; b32 < 2; ++b32) vofs[dt][b32] = KT * 128 + d * 128 + (((4 * b32 + g) ^ f) << 4);
+  }
+
+  unsigned long long atr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tph = ATR_T();
+  const unsigned long long tstart = tph;
+  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  asm volatile("" ::"v"(__builtin_bit_cast(u32x4, qf[0])), "v"(__builtin_bit_cast(u32x4, qf[1])));   // see attn_kernel: keeps vmcnt waits out of the loop head
+  if (ntiles > 1) load_tile(1);
+  __syncthreads();
+  ATR_ADD(0, tph);
+  const int qw0 = a.q_pos0 + q0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const char* st = smem + (kt & 1) * STAGE;
+    if (q0 < a.Sq) {
+      f32x4v sacc[2][2];
+#pragma unroll
+      for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, *(const u32x4*)(st + kofs[b32][t][s]));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc, 0, 0, 0);
+          }
+          sacc[b32][t] = acc;
+        }
+      ATR_ADD(1, tph);
+      const int kbase = kt * KT + 8 * g;                       // kpos(b32, t, i) = kbase + 32 b32 + 4 t + i
+      const float fq = (float)(qpos - kbase);
+      const bool k_left = kt * KT + KT - 1 <= qw0, k_right = kt * KT >= qw0 + 15;
+      if (k_left || k_right) {
+        const float sg = k_left ? 1.0f : -1.0f;
+        const f32x2 sg2 = {sg, sg}, a2 = {-sg * slope2 * fq, -sg * slope2 * fq}, sc2 = {sc, sc};
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const f32x2 bias = __builtin_elementwise_fma(cb[b32][t][i >> 1], sg2, a2);
+              const f32x2 sv = __builtin_elementwise_fma(f32x2{sacc[b32][t][i], sacc[b32][t][i + 1]}, sc2, bias);
+              sacc[b32][t][i] = sv.x; sacc[b32][t][i + 1] = sv.y;
+            }
+      } else {
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float c = (float)(32 * b32 + 4 * t + i);
+              sacc[b32][t][i] = fmaf(sacc[b32][t][i], sc, -slope2 * fabsf(fq - c));
+            }
+      }
+      if (kt == 0 && a.alibi_col0_zero && g == 0) sacc[0][0][0] += slope2 * fabsf(fq);      // key 0 carries no ALiBi bias
+      if (kt * KT + KT > kv_len) {
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              sacc[b32][t][i] = (kbase + 32 * b32 + 4 * t + i < kv_len) ? sacc[b32][t][i] : -1e30f;
+      }
+      float mloc = -1e30f;
+#pragma unroll
+      for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mloc = fmaxf(mloc, sacc[b32][t][i]);
+      mloc = quad_max16(mloc);
+      if (!__all(mloc < m_run - 40.0f)) {                      // same far-tile rule as attn_kernel (2^-40 under every row's maximum)
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        f32x2 ps2 = {0.f, 0.f};
+        const f32x2 mn2 = {m_new, m_new};
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const f32x2 dv = f32x2{sacc[b32][t][i], sacc[b32][t][i + 1]} - mn2;
+              const f32x2 pv = {__builtin_amdgcn_exp2f(dv.x), __builtin_amdgcn_exp2f(dv.y)};
+              sacc[b32][t][i] = pv.x; sacc[b32][t][i + 1] = pv.y;
+              ps2 += pv;
+            }
+        l_run = l_run * alpha + (ps2.x + ps2.y);               // partial over this lane's keys; the 4 lanes of a query merge at the end
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+        }
+        ATR_ADD(2, tph);
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pf[j] = (__bf16)sacc[b32][0][j]; pf[4 + j] = (__bf16)sacc[b32][1][j]; }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, *(const u32x4*)(st + vofs[dt][b32]));
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    ATR_ADD(3, tph);
+    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
+    if (kt + 2 < ntiles) load_tile(kt + 2);
+    ATR_ADD(4, tph);
+    __syncthreads();
+    ATR_ADD(5, tph);
+  }
+#ifdef USDM_ATTN_TRACE
+  if (tid == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 4096) {
+      for (int i = 0; i < 6; ++i) g_attn_trace[wg * 8 + i] = atr[i];
+      g_attn_trace[wg * 8 + 6] = ATR_T() - tstart;
+      g_attn_trace[wg * 8 + 7] = ntiles;
+    }
+  }
+#endif
+  const float l_tot = quad_sum16(l_run);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int qr = q0 + q16;
+  if (qr < a.Sq) {
+    bf16_t* op = (bf16_t*)a.o + (int64_t)b * a.o_bs + (int64_t)qr * a.o_rs + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 o;
+      o.x = pack_bf2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+      o.y = pack_bf2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+      *(uint2*)(op + 16 * dt) = o;
+    }
+  }
+}
 }  // namespace
 
 #ifdef USDM_ATTN_TRACE
@@ -385,6 +646,13 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   const bool ks2 = !small && a.dh == 64 && a.mode == 0 && (ks_env == 2);   // measured: no gain in situ (NFE 5.65 vs 5.58 ms), kept as an experiment switch
   if (ks2) {
     hipLaunchKernelGGL((attn_kernel<64, 0, 4, 2>), grid, dim3(512), 0, st, a2);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
+  // 16-query waves (8 per workgroup) for the Voicebox form: MHA, d = 64, bidirectional (USDM_ATTN_V16=0: the 32-query kernel)
+  const int v16 = getenv("USDM_ATTN_V16") ? atoi(getenv("USDM_ATTN_V16")) : 1;      // read per launch (tools/attn_bench.py flips it)
+  if (v16 && a.dh == 64 && a.mode == 0 && a.Hq == a.Hkv && !small) {
+    hipLaunchKernelGGL((attn16_kernel<8>), grid, dim3(512), 0, st, a2);
     USDM_LAUNCH_CHECK();
     return 0;
   }
