@@ -30,10 +30,25 @@ kinds = {
     "w2*  (same, split-K 4)                 ": lambda W, p: ops.gemm(f16, W, M=R, N=H, Kc=I, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=4, c_split_stride=R * H, plan=p),
     "wo*  (N1024 K1024, split-K 2)          ": lambda W, p: ops.gemm(x16, W, M=R, N=H, Kc=H, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=2, c_split_stride=R * H, plan=p),
 }
-wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo"]
+arena2 = rnd(2, R, H).to(bf)
+Ws["skip"] = [rnd(H, 2 * H, sc=(2 * H) ** -0.5).to(bf) for _ in range(L)]
+skipf = lambda W, p: ops.gemm(arena2, W, M=R, N=H, Kc=H, taps=2, lda=H, rowsA=R, a_tap_stride=R * H, bias=b1, out32=tmp32, out16=o16, ldc=H, plan=p)
+kinds["skip (N1024 K2x1024 two sources)      *"] = skipf
+kinds["skip @tile14                          *"] = skipf
+kinds["skip @tile15                          *"] = skipf
+kinds["wo @tile15                            *"] = kinds["wo   (N1024 K1024, +res f32 out)       "]
+kinds["wo @tile14                            *"] = kinds["wo   (N1024 K1024, +res f32 out)       "]
+wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo", "skip", "skip", "skip", "wo", "wo"]
+if _os.environ.get("VB_ONLY"):
+    keep = [i for i, k in enumerate(kinds) if any(t in k for t in _os.environ["VB_ONLY"].split(","))]
+    kinds = {k: v for i, (k, v) in enumerate(kinds.items()) if i in keep}
+    wkey = [wkey[i] for i in keep]
 tot = 0.0
 for (name, f), wk in zip(kinds.items(), wkey):
     plan = ops.Plan()
+    _os.environ.pop("USDM_GEMM_TILE", None)
+    if "@tile" in name:
+        _os.environ["USDM_GEMM_TILE"] = name.split("@tile")[1].split()[0]
     for W in Ws[wk]:
         f(Ws[wk][0] if _os.environ.get("VB_HOT") else W, plan)
     gp = GraphedPlan(plan)

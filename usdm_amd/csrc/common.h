@@ -72,6 +72,14 @@ __device__ __forceinline__ float half_sum(float v) {
   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
+// sum over the 16-lane DPP row this lane belongs to
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_mov<0xB1>(v));
   v = fmaxf(v, dpp_mov<0x4E>(v));

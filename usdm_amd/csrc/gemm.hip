@@ -826,7 +826,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       const float4 g4 = *(const float4*)(a.ln_gamma + gcol + n), b4 = *(const float4*)(a.ln_beta + gcol + n);
       lg[0] = g4.x; lg[1] = g4.y; lg[2] = g4.z; lg[3] = g4.w; lb[0] = b4.x; lb[1] = b4.y; lb[2] = b4.z; lb[3] = b4.w;
     }
-    float* stp = (PP && C4 == 32 && a.stats_out) ? a.stats_out : nullptr;      // producer form: per-row partial sums of this tile's columns
+    float* stp = (PP && (C4 == 32 || C4 == 16) && a.stats_out) ? a.stats_out : nullptr;      // producer form: per-row partial sums of this tile's columns
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += NB) {
       float4 rres[NB];
@@ -871,10 +871,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
             for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
           }
         }
-        if (stp) {   // the 32 threads that share this row are one half of a wave: reduce, one 8-byte store per row and tile
-          const float s1 = half_sum((v[0] + v[1]) + (v[2] + v[3]));
-          const float s2 = half_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
-          if ((tid & 31) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
+        if (stp) {   // the C4 threads that share this row are one half (BN = 128) or one DPP row (BN = 64) of a wave: reduce, one 8-byte store per row and tile
+          const float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          const float s1 = C4 == 32 ? half_sum(t1) : row16_sum(t1);
+          const float s2 = C4 == 32 ? half_sum(t2) : row16_sum(t2);
+          if ((tid & (C4 - 1)) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
         }
         const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
         if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
@@ -988,7 +989,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   // ... and its 128x128 form where the big tiles would leave half the CUs idle (96-256 tiles of 128x128, one per CU)
   const int64_t t14 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
   static const int pp14 = getenv("USDM_GEMM_PP_SMALL") ? atoi(getenv("USDM_GEMM_PP_SMALL")) : 1;
-  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && a.taps == 1 && a.N > 64 &&   // (K-concatenated sources: measured no gain, 29 vs 30 us)
+  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 &&   // (K-concatenated sources included: the skip Linear 31.1 -> 25.7 us, r03_vb_ablation.txt 8)
                         t12 < 128 && t14 >= 96 && t14 <= 256 &&
                         a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256;
   if (pp_small) sel = 14;
@@ -1014,8 +1015,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
   if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
-    USDM_CHECK_ARG(sel >= 12 && sel <= 14 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
-                       a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
+    USDM_CHECK_ARG(sel >= 12 && sel <= 15 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
+                       a.N % (sel == 15 ? 64 : 128) == 0 && a.groups == 1 && (a.ldc & 3) == 0 && (sel != 15 || a.ln_mode == 0),
                    "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
     USDM_CHECK_ARG(!a.stats_out || (a.act == USDM_ACT_NONE && a.split_k <= 1), "usdm_gemm: stats_out needs a plain, unsplit epilogue");
     USDM_CHECK_ARG(a.ln_mode == 0 || (a.ln_stats && a.ln_nt > 0 && a.ln_nt <= 64 && a.ln_C > 0), "usdm_gemm: ln_stats / ln_nt / ln_C");
@@ -1038,6 +1039,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 12) return launch<bf16_t, 256, 128, 4, 2, true, 3, 2, true>(a, st);   // 8-wave ping-pong loop, one workgroup per CU
     if (sel == 13) return launch<bf16_t, 288, 128, 2, 4, true, 3, 2, true>(a, st);   // row-major epilogues only
     if (sel == 14) return launch<bf16_t, 128, 128, 4, 2, true, 3, 2, true>(a, st);   // the same loop on a 128x128 tile (wave tile 32x64)
+    if (sel == 15) return launch<bf16_t, 192, 64, 2, 4, true, 3, 2, true>(a, st);    // ... and on a 192x64 tile (wave tile 96x16): N = 1024 x 2 236 rows = 192 workgroups
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
