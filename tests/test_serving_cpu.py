@@ -24,8 +24,10 @@ def test_sampling_params_validation_and_greedy_detection():
     for bad in (dict(temperature=-1), dict(top_p=0.0), dict(top_p=1.5), dict(top_k=0), dict(top_k=-2)):
         with pytest.raises(ValueError):
             SamplingParams(**bad)
-    with pytest.raises(NotImplementedError):
-        SamplingParams(n=2)
+    assert SamplingParams(n=2, temperature=0.7).n == 2
+    for bad in (dict(n=2), dict(n=2, temperature=0.0), dict(n=0), dict(n=1.5)):      # greedy copies would be identical (vllm refuses too)
+        with pytest.raises(ValueError):
+            SamplingParams(**bad) if "temperature" in bad or bad["n"] != 2 else SamplingParams(n=2, top_k=1)
 
 
 def test_reference_processors_are_recognised_as_static_masks():

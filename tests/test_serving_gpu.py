@@ -138,6 +138,32 @@ def test_sampled_requests_inside_a_continuous_batch_equal_their_single_runs(dev)
     print("per-slot sampling in a continuous batch:", st)
 
 
+def test_n_completions_per_prompt_are_the_seeded_single_requests(dev):
+    """SamplingParams(n = 3) (vllm surface, src/inference_vllm.py:109-123 passes SamplingParams through unchanged): three
+    completions per prompt, completion j equal to a single request with seed + j, served through the continuous batch together with
+    a greedy request; greedy with n > 1 is refused as vllm does."""
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    from usdm_amd.serving import LLM, SamplingParams
+    sd = MO.random_state_dict(SMALL, seed=50)
+    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256))
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, 1000, (L,), generator=g).tolist() for L in (33, 20)]
+    kw = dict(max_tokens=16, temperature=1.1, top_p=0.95, top_k=40)
+    outs = eng.generate(prompt_token_ids=prompts, sampling_params=[SamplingParams(n=3, seed=100, **kw), SamplingParams(max_tokens=12, top_k=1)])
+    assert len(outs) == 2 and [len(o.outputs) for o in outs] == [3, 1] and [c.index for c in outs[0].outputs] == [0, 1, 2]
+    assert eng.stats["batched_requests"] == 4 and eng.stats["sampled_in_batch"] == 3
+    seqs = [c.token_ids for c in outs[0].outputs]
+    assert len({tuple(t) for t in seqs}) == 3                                          # three different streams
+    for j in range(3):
+        alone = eng.generate(prompt_token_ids=[prompts[0]], sampling_params=SamplingParams(seed=100 + j, **kw))[0].outputs[0].token_ids
+        assert seqs[j] == alone, f"completion {j}: {seqs[j]} != seeded single request {alone}"
+    with pytest.raises(ValueError):
+        SamplingParams(n=2, temperature=0.0)
+    with pytest.raises(ValueError):
+        SamplingParams(n=0)
+
+
 def test_batched_request_running_into_the_context_limit(dev):
     """the reference passes max_tokens = tokenizer.model_max_length, so a greedy sequence that never emits its stop id
     decodes up to the context limit.  In a continuous batch it must stop AT the limit (never append cache rows >= ctx_max, which

@@ -34,8 +34,8 @@ class SamplingParams:
 
     def __init__(self, n=1, temperature=1.0, top_p=1.0, top_k=-1, max_tokens=16, min_tokens=0, stop_token_ids=None,
                  logits_processors=None, seed=None, skip_special_tokens=True, ignore_eos=False, static_logits_mask=None, **unused):
-        if n != 1:
-            raise NotImplementedError("n > 1 (several samples per prompt) is not used by the reference")
+        if not isinstance(n, int) or n < 1:
+            raise ValueError("n must be a positive integer")
         if temperature < 0 or not (0 < top_p <= 1) or (top_k < -1 or top_k == 0):
             raise ValueError("temperature >= 0, 0 < top_p <= 1, top_k = -1 (off) or >= 1")
         self.n, self.temperature, self.top_p, self.top_k = n, float(temperature), float(top_p), int(top_k)
@@ -44,6 +44,8 @@ class SamplingParams:
         self.logits_processors = list(logits_processors or [])
         self.seed, self.skip_special_tokens, self.ignore_eos = seed, skip_special_tokens, ignore_eos
         self.static_logits_mask = static_logits_mask      # None: probe the processors; True / False: caller's word
+        if self.n > 1 and self.greedy:
+            raise ValueError("n must be 1 when using greedy sampling (the n completions would be identical)")   # as vllm
 
     @property
     def greedy(self):
@@ -161,8 +163,13 @@ class LLM:
             seed = sp.seed
             if not sp.greedy and seed is None:      # as generate(): a fresh stream per call, reproducible under torch.manual_seed
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            reqs.append(dict(i=i, rid=str(self._next_id + i), text=text, ids=ids, sp=sp, mask=mask, stops=stops, seed=seed,
-                             max_new=max(0, min(sp.max_tokens, room, self.llm.max_out))))
+            # n > 1 (vllm.SamplingParams.n): the request fans out into n sequences that share prompt, knobs and mask and draw from
+            # the Philox streams seed, seed + 1, ...: completion j is exactly what a single request with seed + j returns, and the
+            # copies ride the continuous batch like any other requests (the prompt is prefilled once per copy)
+            for j in range(sp.n):
+                reqs.append(dict(i=(i, j), rid=str(self._next_id + i), text=text, ids=ids, sp=sp, mask=mask, stops=stops,
+                                 seed=(seed + j) if seed is not None else None,
+                                 max_new=max(0, min(sp.max_tokens, room, self.llm.max_out))))
         self._next_id += n
         self.stats["requests"] += n
         done = {}
@@ -178,7 +185,12 @@ class LLM:
         for r in reqs:
             if r["i"] not in done:
                 done[r["i"]] = self._run_single(r)
-        return [self._finish(r, *done[r["i"]]) for r in reqs]
+        outs = []
+        for r in reqs:
+            if r["i"][1] == 0:
+                outs.append(RequestOutput(r["rid"], r["text"], r["ids"], []))
+            outs[-1].outputs.append(self._finish(r, *done[r["i"]]))
+        return outs
 
     # ------------------------------------------------------------------ one request on the single-sequence graph
     def _run_single(self, r):
@@ -286,4 +298,4 @@ class LLM:
         if self.tokenizer is not None:
             text = self.tokenizer.decode(toks, skip_special_tokens=r["sp"].skip_special_tokens)
         stop_reason = toks[-1] if (why == "stop" and toks) else None
-        return RequestOutput(r["rid"], r["text"], r["ids"], [CompletionOutput(0, text, toks, why, stop_reason)])
+        return CompletionOutput(r["i"][1], text, toks, why, stop_reason)
