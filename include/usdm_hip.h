@@ -169,6 +169,8 @@ typedef struct usdm_attn_args {
   void* o; int64_t o_bs, o_rs;
   const int32_t* kv_len;  /* [B] or NULL (= Skv) */
   const float* slopes;    /* [Hq] or NULL */
+  int32_t window;         /* mode 1: > 0 = sliding window, query at position p sees keys p-window+1 .. p (HF Mistral sliding_window,
+                             src/model.py:337-371); 0 = full causal */
 } usdm_attn_args;
 int usdm_attention(const usdm_attn_args* args, usdm_stream_t stream);
 
@@ -363,6 +365,8 @@ typedef struct usdm_attn_decode_args {
   const int32_t* skip;  /* optional (single-sequence form): *skip != 0 -> return immediately */
   int32_t defer_merge;  /* NS > 1, no counters: leave the partials (pm, pl, po) for the consumer (usdm_gemv mrg_*): no combine
                            launch, `out` is not written */
+  int32_t window;       /* > 0: sliding window, the token at *pos sees keys pos-window+1 .. pos only (the NS splits divide that
+                           range); 0 = the whole cache */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

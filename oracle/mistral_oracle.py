@@ -54,7 +54,11 @@ def forward(sd, cfg, ids, cache=None):
     new_cache = []
     T = past + S
     mask = torch.full((S, T), torch.finfo(dt).min, dtype=dt)
-    mask = mask.masked_fill(torch.arange(T)[None, :] <= pos[:, None], 0)
+    vis = torch.arange(T)[None, :] <= pos[:, None]
+    W = cfg.get("sliding_window")
+    if W:       # HF sliding-window causal mask: query q sees the W keys q-W+1 .. q (reference: src/model.py:337-371 keeps W-1 past keys + the new one)
+        vis = vis & (torch.arange(T)[None, :] > pos[:, None] - W)
+    mask = mask.masked_fill(vis, 0)
     for l in range(cfg["num_hidden_layers"]):
         p = f"model.layers.{l}."
         x = rms_norm(h, sd[p + "input_layernorm.weight"], cfg["rms_norm_eps"])

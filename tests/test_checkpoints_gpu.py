@@ -57,8 +57,8 @@ def test_llm_from_pretrained_streams_hf_sharded_safetensors(dev, tmp_path):
     ref = MO.greedy_generate(sd, LLM_CFG, ids, 12, bad_words_ids=bad)
     out = m.generate(input_ids=ids[None].to(dev), max_new_tokens=12, do_sample=True, top_k=1, bad_words_ids=bad)[0].tolist()
     assert out[:21 + 4] == ref[:21 + 4]                       # (later tokens may differ at bf16 near-ties; covered elsewhere)
-    with pytest.raises(NotImplementedError):
-        USDMForCausalLM.from_pretrained(d, device=dev, ctx_max=8192)     # beyond the 4096 sliding window: refused, not silently wrong
+    big = USDMForCausalLM.from_pretrained(d, device=dev, ctx_max=8192)   # beyond the 4096 sliding window: the kernels bound the key range
+    assert big.window == 4096 and big.ctx_max == 8192 and m.window == 0
 
 
 def _write_w2v(d, n_layers=4):

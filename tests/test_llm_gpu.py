@@ -329,3 +329,66 @@ def test_exact_prefix_reuse_is_bit_identical(dev):
         p = torch.cat([oa, torch.randint(0, 1000, (1, extra), generator=g).to(dev)], 1)
     # rows appended by decode steps were never reused: the reused length never exceeds a previous PROMPT length
     assert all(k[1] in (0, 89, 90, 110, 111, 122) or k[1] <= 122 for k in a._prefill_plans)
+
+
+@pytest.mark.parametrize("W", [40, 64, 100])
+def test_sliding_window_attention_vs_oracle(dev, W):
+    """Mistral's sliding window (reference: src/model.py:337-371; HF mask: query p sees keys p-W+1 .. p) on a context LONGER than
+    the window, small model: (a) prefill logits of a 230-token prompt vs the oracle (rows whose first key tiles are masked entirely,
+    W not a multiple of the 64-key tile), (b) greedy decode across many positions vs the oracle, (c) three chained rounds with exact
+    prefix reuse (prefill with q_pos0 > 0 through the window), (d) four requests through the batched decode of the serving layer.
+    The oracle's window is pinned to the installed transformers in tests/test_oracle_cpu.py."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    from usdm_amd.serving import LLM, SamplingParams
+    cfg = dict(SMALL, sliding_window=W)
+    sd = MO.random_state_dict(cfg, seed=31)
+    m = USDMForCausalLM.from_state_dict(sd, cfg, dev, ctx_max=320)
+    assert m.window == W
+    g = torch.Generator().manual_seed(W)
+    ids = torch.randint(0, 1000, (230,), generator=g)
+    # (a) prefill logits, and the difference the window makes (the test must be able to fail)
+    ref, _ = MO.forward(sd, cfg, ids)
+    full, _ = MO.forward(sd, dict(cfg, sliding_window=None), ids)
+    m.keep_logits = True
+    m.generate(input_ids=ids[None].to(dev), max_new_tokens=1)
+    got = m.last_logits.cpu()
+    scale = ref[-1].abs().max().item()
+    err, werr = (got - ref[-1]).abs().max().item(), (full[-1] - ref[-1]).abs().max().item()
+    print(f"W={W}: prefill logits max err {err:.4f} (scale {scale:.2f}); full-causal logits differ from the windowed ones by {werr:.3f}")
+    assert err <= 4e-2 * scale and werr > 4 * err
+    m.keep_logits = False
+    # (b) + (c): three chained rounds, greedy, vs the oracle on the full prompt
+    bad = [[i] for i in range(0, 200)]
+    p, firsts = ids[:150], []
+    for rnd, (new, extra) in enumerate([(30, 5), (25, 3), (40, 0)]):
+        r, rl = MO.greedy_generate(sd, cfg, p, new, bad_words_ids=bad, return_logits=True)
+        out = m.generate(input_ids=p[None].to(dev), max_new_tokens=new, bad_words_ids=bad)[0].cpu()
+        firsts.append(check_against_oracle(out.tolist(), r, rl, p.numel()))
+        if rnd:
+            assert any(k[1] > 0 for k in m._prefill_plans), "the round did not reuse the cached prefix"
+        p = torch.cat([out, torch.randint(0, 1000, (extra,), generator=g)])
+    # (d) the batched decode
+    eng = LLM(model=m)
+
+    def ban(token_ids, logits):
+        logits[0:200] = float("-inf")
+        return logits
+    prompts = [torch.randint(0, 1000, (L,), generator=g).tolist() for L in (120, 75, 160, 33)]
+    outs = eng.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(max_tokens=20, top_k=1, logits_processors=[ban]))
+    assert eng.stats["batched_requests"] == 4
+    bfirst = []
+    for pr, o in zip(prompts, outs):
+        r, rl = MO.greedy_generate(sd, cfg, torch.tensor(pr), 20, bad_words_ids=bad, return_logits=True)
+        bfirst.append(check_against_oracle(pr + o.outputs[0].token_ids, r, rl, len(pr)))
+    print(f"W={W}: first differences vs the oracle (None = identical): chained rounds {firsts}, batched {bfirst}")
+
+
+def test_window_is_inert_up_to_its_length(dev):
+    from usdm_amd.llm import USDMForCausalLM
+    from oracle import mistral_oracle as MO
+    sd = MO.random_state_dict(SMALL, seed=32)
+    assert USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256).window == 0          # default window 4096 >= ctx_max
+    assert USDMForCausalLM.from_state_dict(sd, dict(SMALL, sliding_window=None), dev, ctx_max=256).window == 0
+    assert USDMForCausalLM.from_state_dict(sd, dict(SMALL, sliding_window=128), dev, ctx_max=256).window == 128

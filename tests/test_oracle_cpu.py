@@ -120,6 +120,19 @@ def test_mistral_oracle_vs_installed_transformers():
                         bad_words_ids=bad, eos_token_id=299, pad_token_id=0)
     mine = MO.greedy_generate(sd, cfg, ids[0], 12, bad_words_ids=bad, eos_token_id=299)
     assert hf[0].tolist() == mine
+    # sliding window shorter than the context (Mistral-7B-v0.1: 4096; reference src/model.py:337-371): prefill logits and generate
+    hf_cfg.sliding_window = 8
+    wcfg = dict(cfg, sliding_window=8)
+    m = transformers.MistralForCausalLM(hf_cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    ids = torch.randint(0, 300, (1, 21), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = m(ids).logits[0].float()
+        hf = m.generate(input_ids=ids, max_length=21 + 14, do_sample=True, top_k=1, top_p=1.0, temperature=1.0,
+                        bad_words_ids=bad, eos_token_id=299, pad_token_id=0)
+    _close(MO.forward(sd, wcfg, ids[0])[0], ref, 2e-5)
+    assert (MO.forward(sd, cfg, ids[0])[0] - ref).abs().max() > 0.1          # the window matters on this input
+    assert hf[0].tolist() == MO.greedy_generate(sd, wcfg, ids[0], 14, bad_words_ids=bad, eos_token_id=299)
 
 
 def test_w2v_oracle_vs_hf_wav2vec2_and_kmeans():

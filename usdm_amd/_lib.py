@@ -81,7 +81,7 @@ class AttnArgs(C.Structure):
         ("k", C.c_void_p), ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
         ("vt", C.c_void_p), ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_ds", C.c_int64),
         ("o", C.c_void_p), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
-        ("kv_len", C.c_void_p), ("slopes", C.c_void_p),
+        ("kv_len", C.c_void_p), ("slopes", C.c_void_p), ("window", C.c_int32),
     ]
 
 
@@ -169,7 +169,7 @@ class AttnDecodeArgs(C.Structure):
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
         ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
         ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64), ("skip", C.c_void_p),
-        ("defer_merge", C.c_int32),
+        ("defer_merge", C.c_int32), ("window", C.c_int32),
     ]
 
 

@@ -118,7 +118,7 @@ def read_mistral_config(path):
     out["rms_norm_eps"] = c.get("rms_norm_eps", 1e-5)
     out["rope_theta"] = float(c.get("rope_theta", 10000.0))
     out["max_position_embeddings"] = c.get("max_position_embeddings", 32768)
-    out["sliding_window"] = c.get("sliding_window") or 4096
+    out["sliding_window"] = c.get("sliding_window", 4096)      # Mistral-7B-v0.1: 4096; an explicit null = full causal attention
     if c.get("tie_word_embeddings"):
         raise NotImplementedError("tied input/output embeddings are not the USDM checkpoint layout")
     return out

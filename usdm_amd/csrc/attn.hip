@@ -105,11 +105,14 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
   }
 
   int kend = kv_len;
+  int kt_lo = 0;                                          // first key tile any query of this workgroup can see
+  const int win = MODE == 1 ? a.window : 0;               // sliding window (causal mode): query p sees keys p-win+1 .. p
   if (MODE == 1) {
     const int last_q = a.q_pos0 + min(qb * QB + QB - 1, a.Sq - 1);
     kend = min(kv_len, last_q + 1);
+    if (win > 0) kt_lo = max(0, a.q_pos0 + qb * QB - win + 1) / KT;
   }
-  const int ntiles = (kend + KT - 1) / KT;
+  const int ntiles = max(0, (kend + KT - 1) / KT - kt_lo);   // tiles kt_lo .. kt_lo + ntiles - 1
 
   // loader mapping: K tile = KT rows x (DH/8) 16-B pieces ; V^T tile = DH rows x 8 pieces
   constexpr int KP = KT * (DH / 8) / NT;  // pieces per thread
@@ -159,19 +162,19 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
   // group-local tile sequence: it-th tile of this group is key tile grp + KS * it
   const int nit = (ntiles + KS - 1) / KS;                  // barrier count is the same for every group
   const int myn = ntiles > grp ? (ntiles - grp + KS - 1) / KS : 0;
-  if (myn > 0) { load_tile(grp); store_tile(0); }
+  if (myn > 0) { load_tile(kt_lo + grp); store_tile(0); }
   // The Q fragments are consumed here on EVERY path into the loop.  Without this the wait-count pass merges the (myn == 0) path,
   // on which the Q loads are still in flight, into the loop header and puts s_waitcnt vmcnt(0) in front of the loop's first MFMAs:
   // every key tile then waits for the prefetch loads issued at the end of the previous tile, i.e. a full L2 / fabric latency per
   // tile with nothing to hide it (found in round 3 from the ISA; profiles/r03_vb_ablation.txt item 7).
 #pragma unroll
   for (int s = 0; s < DS; ++s) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, qf[s])));
-  if (myn > 1) load_tile(grp + KS);
+  if (myn > 1) load_tile(kt_lo + grp + KS);
   __syncthreads();
   ATR_ADD(0, tph);
   for (int it = 0; it < nit; ++it) {
     if (it >= myn) { __syncthreads(); continue; }          // this group has run out of tiles (wave-uniform)
-    const int kt = grp + KS * it;
+    const int kt = kt_lo + grp + KS * it;
     const char* sK = smem + (it & 1) * STAGE;
     const char* sV = sK + KT * KROW;
     // a wave whose 32 queries all lie past the end (the last query block of S = 1118: queries 1120..1151) only helps with the
@@ -230,15 +233,19 @@ __global__ __launch_bounds__(NW * 64 * KS) void attn_kernel(const usdm_attn_args
     if (MODE == 0 && kt == 0 && a.alibi_col0_zero) {          // key 0 carries no ALiBi bias (networks.py:327)
       if (lh == 0) sacc[0][0] = fmaf(sacc[0][0], 1.0f, slope2 * fabsf(fq));
     }
-    const bool need_mask = (kt * KT + KT > kv_len) || (MODE == 1 && kt * KT + KT - 1 > a.q_pos0 + q0);
+    const bool need_mask = (kt * KT + KT > kv_len) || (MODE == 1 && kt * KT + KT - 1 > a.q_pos0 + q0) ||
+                           (win > 0 && kt * KT <= a.q_pos0 + q0 + 31 - win);
     if (need_mask) {
+      // causal mode masks with -inf: with a window a query's FIRST tiles can be masked entirely, and exp2(-1e30 - m_run) is 1, not
+      // 0, while m_run still holds its initial -1e30 (-inf - (-1e30) = -inf -> exactly 0; m_run itself never becomes -inf)
+      const float masked = MODE == 1 ? -__builtin_inff() : -1e30f;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kpos = kbase + 32 * u + (r & 3) + 8 * (r >> 2);
-          const bool ok = (kpos < kv_len) && (MODE == 0 || kpos <= qpos);
-          sacc[u][r] = ok ? sacc[u][r] : -1e30f;
+          const bool ok = (kpos < kv_len) && (MODE == 0 || (kpos <= qpos && (win <= 0 || kpos > qpos - win)));
+          sacc[u][r] = ok ? sacc[u][r] : masked;
         }
     }
 #pragma unroll
@@ -631,6 +638,7 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.Skv_alloc >= cdiv(a.Skv, KT) * KT, "usdm_attention: K/V^T buffers must be allocated (and finite) up to a multiple of %d keys", KT);
   USDM_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_ds % 8 == 0 && a.o_rs % 4 == 0, "usdm_attention: strides break 16-B alignment");
   USDM_CHECK_ARG(a.mode == 0 || a.mode == 1, "usdm_attention: mode");
+  USDM_CHECK_ARG(a.window >= 0 && (a.window == 0 || a.mode == 1), "usdm_attention: window is a causal-mode (mode 1) option, >= 0");
   hipStream_t st = (hipStream_t)stream;
   usdm_attn_args a2 = a;
   if (a2.mode == 0 && a2.head_order == 0) {      // default order of the bidirectional (Voicebox) form; USDM_ATTN_ORDER=0 restores flattest-first

@@ -464,8 +464,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   const int pos = a.pos[bi];
   if ((unsigned)pos >= (unsigned)a.ctx_max) return;   // never append past the cache / rope table (a caller bug: the host bounds every sequence)
   const int ctx = pos + 1;
-  const int chunk = (ctx + NS - 1) / NS;
-  const int k0 = sp * chunk, k1 = min(ctx, k0 + chunk);
+  const int lo = (a.window > 0 && ctx > a.window) ? ctx - a.window : 0;   // sliding window: keys lo .. pos
+  const int chunk = (ctx - lo + NS - 1) / NS;
+  const int k0 = lo + sp * chunk, k1 = min(ctx, k0 + chunk);
   const int nk = max(0, k1 - k0);
   const bf16_t* qkv = (const bf16_t*)a.qkv + (int64_t)bi * a.qkv_bs;
   bf16_t* kcache_b = (bf16_t*)a.kcache + (int64_t)bi * a.cache_bs;
@@ -1005,7 +1006,9 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   USDM_CHECK_ARG(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.NS > 0 && a.NS <= 64, "usdm_attn_decode: heads / NS (<= 64)");
   USDM_CHECK_ARG(a.batch <= 1 || (a.NS > 1 && a.batch <= 64 && a.qkv_bs > 0 && a.out_bs > 0 && a.cache_bs > 0),
                  "usdm_attn_decode: batched form needs NS > 1 and the three strides");
-  USDM_CHECK_ARG(a.NS == 1 || cdiv(a.ctx_max, a.NS) <= DA_KMAX, "usdm_attn_decode: ctx_max/NS exceeds %d keys per split", DA_KMAX);
+  USDM_CHECK_ARG(a.window >= 0 && (a.window == 0 || a.NS > 1), "usdm_attn_decode: window >= 0, and only with the split form (NS > 1)");
+  const int span = (a.window > 0 && a.window < a.ctx_max) ? a.window : a.ctx_max;      // most keys a step can see
+  USDM_CHECK_ARG(a.NS == 1 || cdiv(span, a.NS) <= DA_KMAX, "usdm_attn_decode: visible keys / NS exceeds %d keys per split", DA_KMAX);
   const int G = a.Hq / a.Hkv;
   hipStream_t st = (hipStream_t)stream;
   if (a.NS == 1) {   // single-workgroup-per-kv-head form: no partials, no combine

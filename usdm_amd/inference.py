@@ -133,7 +133,9 @@ def load_models(model_cache_dir, dev=None, ctx_max=None):
     llm_dir = resolve_local(model_cache_dir, "naver-ai/USDM-DailyTalk", must_contain=("config.json",))
     from transformers import AutoTokenizer
     tokenizer = AutoTokenizer.from_pretrained(llm_dir, local_files_only=True)
-    want = ctx_max or min(int(getattr(tokenizer, "model_max_length", 4096) or 4096), 4096)
+    # the reference generates up to tokenizer.model_max_length (inference.py:64); beyond the 4096-token sliding window the attention
+    # kernels bound their key range (llm.py), so the cache may be longer than the window.  8192 = the USDM tokenizer's limit.
+    want = ctx_max or min(int(getattr(tokenizer, "model_max_length", 4096) or 4096), 8192)
     model = USDMForCausalLM.from_pretrained(llm_dir, device=dev, torch_dtype=torch.bfloat16, ctx_max=want).to(dev).eval()
     return model, unit_extractor, voicebox, vocoder, tokenizer
 

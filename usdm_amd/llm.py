@@ -111,11 +111,11 @@ class USDMForCausalLM:
         V = c["vocab_size"]
         self.Vloc, self.v0, self.v1, self.nparts = vocab_shard(V, tp_rank, tp_size)
         self.ctx_max = (ctx_max + 63) // 64 * 64
-        if self.ctx_max > c.get("sliding_window", 4096):
-            # Mistral-7B-v0.1 attends to the last 4096 positions only (reference: src/model.py:337-341, HF sliding_window);
-            # the kernels here implement full causal attention, which is the same thing up to 4096 tokens and not beyond
-            raise NotImplementedError(f"ctx_max {self.ctx_max} exceeds the sliding window ({c.get('sliding_window', 4096)}): "
-                                      "sliding-window attention is not implemented")
+        # Mistral-7B-v0.1 attends to the last `sliding_window` (4096) positions only (reference: src/model.py:337-371 keeps
+        # W - 1 past keys + the new one; HF sliding-window mask: query p sees keys p-W+1 .. p).  The caches here keep every row up
+        # to ctx_max and the attention kernels take the window as a key-range bound, so nothing changes while ctx_max <= W.
+        W = c.get("sliding_window", 4096)
+        self.window = int(W) if (W and self.ctx_max > int(W)) else 0
         # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
         # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
         # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
@@ -392,13 +392,13 @@ class USDMForCausalLM:
                                ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=vt, vt_ld=Spad, plan=plan)
                 ops.attention(qkv, slot.kcache[l], vt, ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=S, Skv_alloc=Spad,
                               q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d), v_strides=(0, d * Spad, Spad),
-                              o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
+                              o_strides=(0, Hq * d), scale=d ** -0.5, window=self.window, plan=plan)
             else:
                 ops.rope_cache(qkv, self.cos, self.sin, self.kcache[l], self.vcache[l], ld=nq, S=S, pos0=past, Hq=Hq, Hkv=Hkv,
                                ctx_max=self.ctx_max, max_pos=self.ctx_max, vt=self.vtc[l][:, :, past:], vt_ld=self.ctx_max, plan=plan)
                 ops.attention(qkv, self.kcache[l], self.vtc[l], ao, mode=1, dh=d, B=1, Hq=Hq, Hkv=Hkv, Sq=S, Skv=past + S,
                               Skv_alloc=self.ctx_max, q_pos0=past, q_strides=(0, d, nq), k_strides=(0, self.ctx_max * d, d),
-                              v_strides=(0, d * self.ctx_max, self.ctx_max), o_strides=(0, Hq * d), scale=d ** -0.5, plan=plan)
+                              v_strides=(0, d * self.ctx_max, self.ctx_max), o_strides=(0, Hq * d), scale=d ** -0.5, window=self.window, plan=plan)
             if tp == 1:
                 ops.gemm(ao, w["o"], M=S, N=H, Kc=Hq * d, residual=h, ldr=H, round_bf16=True, out16=h, plan=plan)
             else:
@@ -448,7 +448,7 @@ class USDMForCausalLM:
             w = self.W["layers"][l]
             ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, defer_merge=mrg is not None, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, defer_merge=mrg is not None, window=self.window, plan=plan)
             plan = row_parallel(plan, w["o"], ao, Hq * d, 2 * l, merge=mrg)
             ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, skip=skp, plan=plan)
             plan = row_parallel(plan, w["down"], act, I, 2 * l + 1)
@@ -493,7 +493,7 @@ class USDMForCausalLM:
                 if l == 0 or self.chain == 3:
                     ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
                 ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                                ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, plan=plan)
+                                ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, skip=skp, window=self.window, plan=plan)
                 ph = [G(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h),
                       G(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act),
                       G(w["down"], act, N=H, K=I, residual=h, y16=h)]
@@ -517,7 +517,7 @@ class USDMForCausalLM:
                 ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
             mrg = (pm, pl, po, self.NS) if (self.merge_in_oproj and cnt is None) else None
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, defer_merge=mrg is not None, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, defer_merge=mrg is not None, window=self.window, plan=plan)
             if tp == 1:
                 ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, merge=mrg, plan=plan)
             else:
@@ -608,7 +608,7 @@ class USDMForCausalLM:
             w = self.W["layers"][l]
             ops.gemv_batch(w["qkv"], h, nb=B, N=nq, K=H, x_bs=H, y_bs=nq, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, bb["pos"], self.cos, self.sin, bb["kc"][0, l], bb["vc"][0, l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, plan=plan)
+                            ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, window=self.window, plan=plan)
             ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
             ops.gemv_batch(w["gu"], h, nb=B, N=2 * I, K=H, x_bs=H, y_bs=I, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU,
                            y16=act, plan=plan)

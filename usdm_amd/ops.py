@@ -141,7 +141,7 @@ def aa_snake(x, alpha, beta, fup, fdn, *, T, C, Creal=None, logscale=True, out32
 
 
 def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_strides, k_strides, v_strides, o_strides,
-              scale=1.0, q_pos0=0, kv_len=None, slopes=None, alibi_col0_zero=True, plan=None):
+              scale=1.0, q_pos0=0, kv_len=None, slopes=None, alibi_col0_zero=True, window=0, plan=None):
     """usdm_attention (see include/usdm_hip.h for layouts)."""
     _need_cuda(q, k, vt, o, kv_len, slopes)
     a = AttnArgs()
@@ -152,6 +152,7 @@ def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_stride
     a.vt, (a.v_bs, a.v_hs, a.v_ds) = _ptr(vt), v_strides
     a.o, (a.o_bs, a.o_rs) = _ptr(o), o_strides
     a.kv_len, a.slopes = _ptr(kv_len), _ptr(slopes)
+    a.window = int(window)
     _go(plan, "usdm_attention", lib.usdm_attention, C_.byref(a))
 
 
@@ -362,7 +363,7 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
 
 
 def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,
-                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, defer_merge=False, plan=None):
+                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, defer_merge=False, window=0, plan=None):
     _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
@@ -370,6 +371,7 @@ def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv,
     a.pm, a.pl, a.po, a.out, a.counters = _ptr(pm), _ptr(pl), _ptr(po), _ptr(out), _ptr(counters)
     a.batch, a.qkv_bs, a.out_bs, a.cache_bs, a.skip = batch, qkv_bs, out_bs, cache_bs, _ptr(skip)
     a.defer_merge = int(defer_merge)
+    a.window = int(window)
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 

@@ -110,7 +110,7 @@ class LLM:
             if tokenizer is None:
                 from transformers import AutoTokenizer
                 tokenizer = AutoTokenizer.from_pretrained(path, local_files_only=True)
-            ctx = min(int(max_model_len or getattr(tokenizer, "model_max_length", 4096) or 4096), 4096)
+            ctx = min(int(max_model_len or getattr(tokenizer, "model_max_length", 4096) or 4096), 8192)
             self.llm = USDMForCausalLM.from_pretrained(path, device=device, ctx_max=ctx)
         if isinstance(tokenizer, str):
             from transformers import AutoTokenizer
