@@ -35,10 +35,8 @@ Ws["skip"] = [rnd(H, 2 * H, sc=(2 * H) ** -0.5).to(bf) for _ in range(L)]
 skipf = lambda W, p: ops.gemm(arena2, W, M=R, N=H, Kc=H, taps=2, lda=H, rowsA=R, a_tap_stride=R * H, bias=b1, out32=tmp32, out16=o16, ldc=H, plan=p)
 kinds["skip (N1024 K2x1024 two sources)      *"] = skipf
 kinds["skip @tile14                          *"] = skipf
-kinds["skip @tile15                          *"] = skipf
-kinds["wo @tile15                            *"] = kinds["wo   (N1024 K1024, +res f32 out)       "]
 kinds["wo @tile14                            *"] = kinds["wo   (N1024 K1024, +res f32 out)       "]
-wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo", "skip", "skip", "skip", "wo", "wo"]
+wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo", "skip", "skip", "wo"]
 if _os.environ.get("VB_ONLY"):
     keep = [i for i, k in enumerate(kinds) if any(t in k for t in _os.environ["VB_ONLY"].split(","))]
     kinds = {k: v for i, (k, v) in enumerate(kinds.items()) if i in keep}

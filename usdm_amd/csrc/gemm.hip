@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   constexpr int PBA = BM / 8, PBB = BN / 8;
   constexpr int PFA = PBA / NWV, PLA = PBA % NWV, PFB = PBB / NWV;
   constexpr int PNF = PFA + PFB, NPW = PNF + (PLA ? 1 : 0);
-  static_assert(!PP || (PBB % NWV == 0 && (PLA == 0 || PLA == 4) && PNF % 2 == 0), "ping-pong DMA split");
+  static_assert(!PP || (PBB % NWV == 0 && (PLA == 0 || PLA == 4) && PNF >= 2), "ping-pong DMA split");   // odd PNF: the second phase issues one instruction more
   unsigned pofs[PNF + 1];                                // source byte offsets at chunk 0 (>= 2^31: row out of range): A..., W..., leftover A
   unsigned phi = 0;                                      // bit i: instruction i of this lane fetches a piece of the SECOND half of the step
   if constexpr (PP) {
@@ -1015,8 +1015,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
   if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
-    USDM_CHECK_ARG(sel >= 12 && sel <= 15 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
-                       a.N % (sel == 15 ? 64 : 128) == 0 && a.groups == 1 && (a.ldc & 3) == 0 && (sel != 15 || a.ln_mode == 0),
+    USDM_CHECK_ARG(sel >= 12 && sel <= 14 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
+                       a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
                    "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
     USDM_CHECK_ARG(!a.stats_out || (a.act == USDM_ACT_NONE && a.split_k <= 1), "usdm_gemm: stats_out needs a plain, unsplit epilogue");
     USDM_CHECK_ARG(a.ln_mode == 0 || (a.ln_stats && a.ln_nt > 0 && a.ln_nt <= 64 && a.ln_C > 0), "usdm_gemm: ln_stats / ln_nt / ln_C");
@@ -1039,7 +1039,6 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 12) return launch<bf16_t, 256, 128, 4, 2, true, 3, 2, true>(a, st);   // 8-wave ping-pong loop, one workgroup per CU
     if (sel == 13) return launch<bf16_t, 288, 128, 2, 4, true, 3, 2, true>(a, st);   // row-major epilogues only
     if (sel == 14) return launch<bf16_t, 128, 128, 4, 2, true, 3, 2, true>(a, st);   // the same loop on a 128x128 tile (wave tile 32x64)
-    if (sel == 15) return launch<bf16_t, 192, 64, 2, 4, true, 3, 2, true>(a, st);    // ... and on a 192x64 tile (wave tile 96x16): N = 1024 x 2 236 rows = 192 workgroups
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);
