@@ -1,14 +1,18 @@
-// Flash-style attention forward on bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 online softmax.
+// Flash-style attention forward on bf16 MFMA, fp32 online softmax.
 //
 // Replaces, without materialising any [S,S] tensor:
 //   * Voicebox Attention.forward + the ALiBi/padding bias built in Transformer.forward
 //     (networks.py:162-210, 319-341): bidirectional, bias = -slope_h*|i-j| with key column 0 = 0
-//   * HF Mistral causal GQA attention in prefill (third-party)
+//   * HF Mistral causal GQA attention in prefill (third-party), with the sliding window of
+//     src/model.py:337-371 as a key-range bound (usdm_attn_args.window)
 //
 // Orientation (CDNA4-specific): the wave computes S^T = K.Q^T, so one lane owns one QUERY column
-// and the softmax statistics are lane-local; the exponentiated accumulator tile is then fed
-// straight back as the B operand of O^T += V^T.P^T (no LDS round trip, no cross-lane traffic).
+// and the softmax statistics are lane-local (attn_kernel, v_mfma_f32_32x32x16_bf16) or shared by 4 lanes (attn16_kernel,
+// v_mfma_f32_16x16x32_bf16); the exponentiated accumulator tile is then fed straight back as the B operand of
+// O^T += V^T.P^T (no LDS round trip, no cross-lane traffic).
 // V is therefore consumed as V^T [d][key], which the producing GEMM epilogue writes directly.
+//   attn_kernel   : 4 waves x 32 queries per workgroup; every form (d = 64 / 128, bidirectional / causal, GQA)
+//   attn16_kernel : 8 waves x 16 queries; the Voicebox form (d = 64, MHA, bidirectional), default since round 3
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/usdm_hip.h"
