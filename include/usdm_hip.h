@@ -267,6 +267,14 @@ typedef struct usdm_gemv_args {
    * w_s = exp(pm[h][s] - max_s pm[h][s]).  Replaces the separate combine launch (the prologue runs while this launch's first
    * weight loads are in flight).  K = heads*128; mrg_ns splits per head. */
   const float* mrg_pm; const float* mrg_pl; const float* mrg_po; int32_t mrg_ns;
+  /* o_proj of the decode step, hand-off form (round 3): with cmb_gran the mrg_* partials are combined ONCE per head, by the
+   * first K/128 workgroups of THIS launch (the arithmetic of the combine kernel, bit for bit), and handed to all workgroups as
+   * 8-byte granules {tag 1, 2 x bf16} in cmb_gran[K/2] (device memory; its tags must be zero when the launch starts:
+   * usdm_attn_decode(cmb_gran) clears them).  Every workgroup requests its first weight ring BEFORE it waits for the granules,
+   * so the combine runs under the weight latency instead of in a launch of its own.  The wait is bounded (cmb_timeout_ms of the
+   * 100 MHz clock); on expiry the workgroup ORs 1 into *cmb_err and carries on with zeros.  N = 16 * 256 outputs only (one
+   * 16-wave workgroup per CU, all co-resident). */
+  unsigned long long* cmb_gran; int32_t* cmb_err; int32_t cmb_timeout_ms;
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);
 int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head mode writes */
@@ -367,6 +375,7 @@ typedef struct usdm_attn_decode_args {
                            launch, `out` is not written */
   int32_t window;       /* > 0: sliding window, the token at *pos sees keys pos-window+1 .. pos only (the NS splits divide that
                            range); 0 = the whole cache */
+  unsigned long long* cmb_gran;  /* optional: the Hq*64 granules of usdm_gemv's cmb_gran hand-off, cleared by this launch */
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 

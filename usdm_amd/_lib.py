@@ -114,6 +114,7 @@ class GemvArgs(C.Structure):
         ("x_delta", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p),
         ("p2p", C.c_void_p), ("p2p_site", C.c_int32), ("p2p_mode", C.c_int32),
         ("mrg_pm", C.c_void_p), ("mrg_pl", C.c_void_p), ("mrg_po", C.c_void_p), ("mrg_ns", C.c_int32),
+        ("cmb_gran", C.c_void_p), ("cmb_err", C.c_void_p), ("cmb_timeout_ms", C.c_int32),
     ]
 
 
@@ -169,7 +170,7 @@ class AttnDecodeArgs(C.Structure):
         ("kcache", C.c_void_p), ("vcache", C.c_void_p),
         ("pm", C.c_void_p), ("pl", C.c_void_p), ("po", C.c_void_p), ("out", C.c_void_p), ("counters", C.c_void_p),
         ("batch", C.c_int32), ("qkv_bs", C.c_int64), ("out_bs", C.c_int64), ("cache_bs", C.c_int64), ("skip", C.c_void_p),
-        ("defer_merge", C.c_int32), ("window", C.c_int32),
+        ("defer_merge", C.c_int32), ("window", C.c_int32), ("cmb_gran", C.c_void_p),
     ]
 
 

@@ -47,7 +47,9 @@ __device__ unsigned long long g_gemv_trace[8192 * 8];
 // slower, profiles/r02_decode_ablation.txt).
 // P2P: the fused peer-to-peer all-reduce epilogue (tensor-parallel decode) is likewise its own instantiation, so the single-GPU
 // kernels carry none of it.
-template <int RW, bool GLU, int NWV, bool MRG = false, bool P2P = false>
+// CMB: the hand-off form of the merged-attention input (usdm_gemv_args.cmb_gran): one combine per head by the launch's first
+// workgroups, granules to everyone, the wait under the first weight ring.  Its own instantiation for the same reason.
+template <int RW, bool GLU, int NWV, bool MRG = false, bool P2P = false, bool CMB = false>
 __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) {
   constexpr int NTH = NWV * 64;
   constexpr int NR = GLU ? 2 * RW : RW;   // rows streamed together by one wave
@@ -164,6 +166,59 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
         }
       }
       *(u32x4*)(xs + i) = o;
+    }
+  } else if constexpr (CMB) {
+    // ---- (1) the first K/128 workgroups combine one head each: attn_combine_kernel's arithmetic on threads 0..127
+    const int NS = a.mrg_ns;
+    float* cw = (float*)smem;                                // [64] split weights + [1] 1/l (the x staging area is still free)
+    if ((int)blockIdx.x < (K >> 7)) {
+      const int hq = blockIdx.x, d = tid;
+      if (d < 64) {
+        const float mv = d < NS ? a.mrg_pm[hq * NS + d] : -1e30f;
+        const float m = wave_max(mv);
+        const float e = d < NS ? __expf(mv - m) : 0.f;
+        const float l = wave_sum(d < NS ? a.mrg_pl[hq * NS + d] * e : 0.f);
+        cw[d] = e;
+        if (d == 0) cw[64] = 1.0f / l;
+      }
+      __syncthreads();
+      if (d < 128) {
+        const float* p = a.mrg_po + (int64_t)hq * NS * 128 + d;
+        float o = 0.f;
+        int s = 0;
+        for (; s + 4 <= NS; s += 4) {
+          const float a0 = p[(s + 0) * 128], a1 = p[(s + 1) * 128], a2 = p[(s + 2) * 128], a3 = p[(s + 3) * 128];
+          o += (a0 * cw[s] + a1 * cw[s + 1]) + (a2 * cw[s + 2] + a3 * cw[s + 3]);
+        }
+        for (; s < NS; ++s) o += p[s * 128] * cw[s];
+        const unsigned v = f2bf(o * cw[64]);
+        const unsigned hi = __shfl_down(v, 1, 64);           // element d + 1 (d even: same wave)
+        if (!(d & 1))
+          __hip_atomic_store(a.cmb_gran + hq * 64 + (d >> 1), (1ull << 32) | (unsigned long long)(v | (hi << 16)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();                                       // cw is dead before the gather overwrites the staging area
+    }
+    // ---- (2) every workgroup gathers the K/2 granules into its LDS copy of x (bounded re-reads of the ones not there yet)
+    {
+      const unsigned long long tmo = (unsigned long long)(a.cmb_timeout_ms > 0 ? a.cmb_timeout_ms : 200) * 100000ull;
+      const unsigned long long t0 = wall_clock64();
+      bool late = false;
+      for (int i = tid; i < (Kpad >> 1); i += NTH) {
+        unsigned val = 0u;
+        if (i < (K >> 1)) {
+          unsigned long long g = __hip_atomic_load(a.cmb_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spins = 0;
+          while ((unsigned)(g >> 32) != 1u && !late) {
+            __builtin_amdgcn_s_sleep(1);
+            g = __hip_atomic_load(a.cmb_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((++spins & 63) == 63 && wall_clock64() - t0 > tmo) late = true;
+          }
+          val = (unsigned)(g >> 32) == 1u ? (unsigned)g : 0u;
+        }
+        *(unsigned*)(xs + 2 * i) = val;
+      }
+      if (late && a.cmb_err) atomicOr((int*)a.cmb_err, 1);
     }
   } else if constexpr (MRG) {
     // o_proj of the decode step: x is MERGED here from the context-split attention partials (usdm_gemv_args.mrg_*), four
@@ -463,6 +518,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = a.pos[bi];
   if ((unsigned)pos >= (unsigned)a.ctx_max) return;   // never append past the cache / rope table (a caller bug: the host bounds every sequence)
+  if (a.cmb_gran) {   // clear the tags of the o_proj hand-off granules (usdm_gemv cmb_gran) for the launch that follows
+    const int gi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 256 + tid;
+    if (bi == 0 && gi < a.Hq * 64) a.cmb_gran[gi] = 0ull;
+  }
   const int ctx = pos + 1;
   const int lo = (a.window > 0 && ctx > a.window) ? ctx - a.window : 0;   // sliding window: keys lo .. pos
   const int chunk = (ctx - lo + NS - 1) / NS;
@@ -888,6 +947,14 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   const size_t lds = (size_t)Kpad * 2;
   // Wide workgroups for the mid-size projections: one workgroup per CU with 12-16 waves stages x (and the fused
   // RMSNorm) once per 16-24 rows instead of once per 4, at the same number of loads in flight.
+  if (a.cmb_gran) {   // hand-off form of the merged-attention input
+    USDM_CHECK_ARG(a.mrg_po && a.mrg_pm && a.mrg_pl && a.mrg_ns >= 1 && a.mrg_ns <= 64 && !a.p2p_mode && !glu && !a.part_val && !a.norm_w && !a.x_delta &&
+                       nout % 256 == 0 && nout / 256 == 16 && a.K % 128 == 0 && a.K / 128 <= 256,
+                   "usdm_gemv: cmb_gran needs the mrg_* partials, a plain 4096-output projection and K / 128 <= 256 heads");
+    hipLaunchKernelGGL((gemv_kernel<1, false, 16, false, false, true>), dim3(256), dim3(1024), lds, st, a);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.mrg_po || a.p2p_mode) {   // o_proj with the attention merge in its prologue and / or a row-parallel projection with the
     // peer-to-peer all-reduce in its epilogue: the 4096-output shape of the 7B (one 16-wave workgroup per CU) or the general form
     USDM_CHECK_ARG(!glu && !a.part_val, "usdm_gemv: merged-attention input / fused all-reduce are for plain projections");

@@ -125,6 +125,11 @@ class USDMForCausalLM:
         # wants make the latency-bound split kernel slower (rank-0-of-8 proxy: 1.10 -> 1.23 ms/token).  USDM_ATTN_MERGE_IN_OPROJ=1
         # enables it.
         self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
+        # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
+        # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
+        # shape only (4096 outputs = one 16-wave workgroup per CU).  USDM_ATTN_CMB=0 restores the combine kernel.
+        self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
+                    and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
         dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
         if self.NS == 1:
@@ -485,6 +490,9 @@ class USDMForCausalLM:
             return h_alt if cur is self.h_dec else self.h_dec
 
         skp = self.st_done   # decode kernels return at once after a device-side EOS (see _alloc)
+        cmb_gran = Z(L, Hq * 64, dt=torch.int64) if self.cmb else None      # one granule block per layer (tags cleared by the layer's attention launch)
+        if self.cmb and not hasattr(self, "cmb_err"):
+            self.cmb_err = torch.zeros(1, dtype=torch.int32, device=dev)
 
         if tp == 1 and self.chain in (3, 4) and cnt is None and not self.merge_in_oproj:
             G = lambda *a_, **k_: ops.gemv(*a_, skip=skp, only_args=True, **k_)
@@ -515,11 +523,14 @@ class USDMForCausalLM:
                 h, pend = flip(h), None
             else:
                 ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
-            mrg = (pm, pl, po, self.NS) if (self.merge_in_oproj and cnt is None) else None
+            use_cmb = self.cmb and tp == 1 and cnt is None and self.NS > 1
+            mrg = (pm, pl, po, self.NS) if ((self.merge_in_oproj or use_cmb) and cnt is None) else None
+            gran = cmb_gran[l] if use_cmb else None
             ops.attn_decode(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, defer_merge=mrg is not None, window=self.window, plan=plan)
+                            ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, counters=cnt, skip=skp, defer_merge=mrg is not None, window=self.window,
+                            cmb_gran=gran, plan=plan)
             if tp == 1:
-                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, merge=mrg, plan=plan)
+                ops.gemv(w["o"], ao, N=H, K=Hq * d, residual=h, y16=h, skip=skp, merge=mrg, cmb=(gran, self.cmb_err) if use_cmb else None, plan=plan)
             else:
                 ops.gemv(w["o"], ao, N=H, K=Hq * d, round_bf16=False, y32=part, skip=skp, merge=mrg, plan=plan)
                 segs += [plan, (lambda t=part: self._all_reduce(t))]
@@ -792,6 +803,9 @@ class USDMForCausalLM:
             if self.chain and int(self.chain_sync[:, 1].sum().item()):
                 raise RuntimeError("usdm_gemv_chain: a grid barrier timed out (the persistent decode kernel was not fully resident); "
                                    "results are invalid - rerun with USDM_GEMV_CHAIN=0")
+            if getattr(self, "cmb_err", None) is not None and int(self.cmb_err.item()):
+                raise RuntimeError("usdm_gemv (cmb_gran): the in-launch attention hand-off timed out (the o_proj launch was not fully "
+                                   "resident); results are invalid - rerun with USDM_ATTN_CMB=0")
             hit = [i for i, t in enumerate(toks) if t in eos and i + 1 >= min_new_tokens]
             if hit:
                 toks = toks[:hit[0] + 1]

@@ -225,7 +225,7 @@ def process_unit(units, rep, hop):
 
 def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True, residual=None, y16=None, y32=None,
          ban=None, part_val=None, part_idx=None, idx_offset=0, x_delta=None, x_out=None, skip=None, p2p=None, p2p_site=0,
-         p2p_mode=0, merge=None, plan=None, only_args=False):
+         p2p_mode=0, merge=None, cmb=None, plan=None, only_args=False):
     """usdm_gemv: batch-1 weight-streaming GEMV (see include/usdm_hip.h).  p2p: a usdm_amd.p2p.P2PComm (fused all-reduce).
     only_args=True: return the filled usdm_gemv_args instead of launching (a phase of usdm_gemv_chain)."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx, x_delta, x_out, skip)
@@ -242,6 +242,12 @@ def gemv(W, x, *, N, K, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
         pm, pl, po, ns = merge
         _need_cuda(pm, pl, po)
         a.mrg_pm, a.mrg_pl, a.mrg_po, a.mrg_ns = _ptr(pm), _ptr(pl), _ptr(po), ns
+    if cmb is not None:         # (granules int64 [K/2], err int32 [1]): the hand-off form of `merge` (one combine per head, see usdm_hip.h)
+        gran, err = cmb
+        _need_cuda(gran, err)
+        if merge is None or gran.numel() * gran.element_size() < (K // 2) * 8:
+            raise ValueError("usdm_gemv: cmb needs merge=(pm, pl, po, NS) and K/2 8-byte granules")
+        a.cmb_gran, a.cmb_err, a.cmb_timeout_ms = _ptr(gran), _ptr(err), 200
     if p2p is not None and p2p_mode:
         p2p.check_site(p2p_site, N)
         a.p2p, a.p2p_site, a.p2p_mode = p2p.dev_ptr, p2p_site, p2p_mode
@@ -363,7 +369,7 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
 
 
 def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,
-                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, defer_merge=False, window=0, plan=None):
+                qkv_bs=0, out_bs=0, cache_bs=0, skip=None, defer_merge=False, window=0, cmb_gran=None, plan=None):
     _need_cuda(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, counters)
     a = AttnDecodeArgs()
     a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
@@ -372,6 +378,11 @@ def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv,
     a.batch, a.qkv_bs, a.out_bs, a.cache_bs, a.skip = batch, qkv_bs, out_bs, cache_bs, _ptr(skip)
     a.defer_merge = int(defer_merge)
     a.window = int(window)
+    if cmb_gran is not None:
+        _need_cuda(cmb_gran)
+        if cmb_gran.numel() * cmb_gran.element_size() < Hq * 64 * 8:
+            raise ValueError("usdm_attn_decode: cmb_gran holds Hq*64 8-byte granules")
+        a.cmb_gran = _ptr(cmb_gran)
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
