@@ -379,26 +379,6 @@ typedef struct usdm_attn_decode_args {
 } usdm_attn_decode_args;
 int usdm_attn_decode(const usdm_attn_decode_args* args, usdm_stream_t stream);
 
-/* Decode attention + the merge of its partials + the o_proj projection that consumes it, in ONE launch (round 3; replaces
- * usdm_attn_decode + usdm_gemv for the attention half of a decode layer, the HF MistralAttention.forward of one token incl.
- * o_proj and the residual add, src/inference.py:63-83 -> transformers modeling_mistral).  Workgroup i = (kv head i % Hkv,
- * context split i / Hkv) and owns output rows 16 i .. 16 i + 15 of the projection: it requests those weight rows first and
- * computes its attention partial while they travel; partials and the merged head outputs are handed between workgroups as
- * 8-byte granules tagged *epoch + 1 (usdm_epoch_inc once per decode step, before the step's first usdm_attn_oproj).
- * attn: as usdm_attn_decode with 2 <= NS <= 32, batch <= 1, no counters; pm / pl / po / out unused.
- * gemv: plain projection, W [N][ldw], K = Hq * 128 <= 4096, N = 16 * Hkv * NS, residual / y16 / y32 / round_bf16 as usdm_gemv; x unused.
- * part_gran [Hq][NS][130], x_gran [K / 2]: device scratch of THIS layer.  All Hkv * NS workgroups must be co-resident (<= CUs).
- * Waits are bounded (timeout_ms): on expiry *err |= 1 and zeros are used.  Results are bit-identical to the separate launches. */
-typedef struct usdm_attn_oproj_args {
-  usdm_attn_decode_args attn;
-  usdm_gemv_args gemv;
-  unsigned long long* part_gran; unsigned long long* x_gran;
-  const uint32_t* epoch; int32_t* err; int32_t timeout_ms;
-} usdm_attn_oproj_args;
-int usdm_attn_oproj(const usdm_attn_oproj_args* args, usdm_stream_t stream);
-int usdm_epoch_inc(uint32_t* epoch, usdm_stream_t stream);   /* *epoch += 1 on the stream */
-int usdm_sizeof_attn_oproj_args(void);
-
 /* ------------------------------------------------------------------------------------------------
  * One-shot peer-to-peer all-reduce for the tensor-parallel decode step (replaces the single-GPU
  * model.generate of src/inference.py:116-123 when the 7B is sharded over the 8 GPUs of a node).  Messages are 4096 f32

@@ -174,11 +174,6 @@ class AttnDecodeArgs(C.Structure):
     ]
 
 
-class AttnOprojArgs(C.Structure):
-    _fields_ = [("attn", AttnDecodeArgs), ("gemv", GemvArgs), ("part_gran", C.c_void_p), ("x_gran", C.c_void_p),
-                ("epoch", C.c_void_p), ("err", C.c_void_p), ("timeout_ms", C.c_int32)]
-
-
 def check(rc, what=""):
     if rc != 0:
         raise UsdmError(f"{what} failed (rc={rc}): {lib.usdm_last_error().decode()}")
@@ -192,7 +187,7 @@ def _selfcheck():
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
                       ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs),
-                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev), ("gemv_chain", GemvChainArgs), ("attn_oproj", AttnOprojArgs)):
+                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev), ("gemv_chain", GemvChainArgs)):
         n = getattr(lib, f"usdm_sizeof_{name}" if name in ("decode_state", "p2p_dev") else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

@@ -130,17 +130,22 @@ class USDMForCausalLM:
         # shape only (4096 outputs = one 16-wave workgroup per CU).  USDM_ATTN_CMB=0 restores the combine kernel.
         self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
                     and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
-        # One launch for the attention half of a decode layer (usdm_attn_oproj: context-split attention, merge, o_proj, residual; the
-        # weight rows of o_proj travel while the attention runs).  Needs hidden = 16 * Hkv * NS rows (7B: 8 x 32 x 16 = 4096),
-        # head_dim 128, Hq * 128 <= 4096, one GPU.  USDM_ATTN_OPROJ=0 restores the separate launches.
-        self.fused_ao = (os.environ.get("USDM_ATTN_OPROJ", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
-                         and c["head_dim"] == 128 and self.Hq * 128 <= 4096 and self.Hq // self.Hkv in (1, 2, 4)
-                         and c["hidden_size"] % (16 * self.Hkv) == 0 and 2 <= c["hidden_size"] // (16 * self.Hkv) <= 32)
+        # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
+        # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
+        # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
+        # Measured (profiles/r02_decode_ablation.txt) and OFF by default: on the single-GPU 7B shapes the merge costs the o_proj
+        # launch more than the combine launch it removes (2.97 -> 3.10 ms/token at NS = 8: 128 KB of partials per workgroup and
+        # two dependent L2 round trips no longer hide under the weight ring; NS = 32: 3.28), and the fewer, fatter splits it
+        # wants make the latency-bound split kernel slower (rank-0-of-8 proxy: 1.10 -> 1.23 ms/token).  USDM_ATTN_MERGE_IN_OPROJ=1
+        # enables it.
+        self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
+        # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
+        # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
+        # shape only (4096 outputs = one 16-wave workgroup per CU).  USDM_ATTN_CMB=0 restores the combine kernel.
+        self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
+                    and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
         dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
-        if self.fused_ao and decode_splits is None and "USDM_DECODE_SPLITS" not in os.environ:
-            self.NS = c["hidden_size"] // (16 * self.Hkv)          # the fused launch fixes the split count: one workgroup per 16 output rows
-        self.fused_ao = self.fused_ao and self.NS == c["hidden_size"] // (16 * self.Hkv) and -(-min(self.ctx_max, self.window or self.ctx_max) // self.NS) <= 512
         if self.NS == 1:
             self.merge_in_oproj = False          # one workgroup per kv head: nothing to merge
         # Chained decode GEMVs (usdm_gemv_chain): consecutive projections of a layer in ONE persistent launch whose weight stream
@@ -499,18 +504,7 @@ class USDMForCausalLM:
             return h_alt if cur is self.h_dec else self.h_dec
 
         skp = self.st_done   # decode kernels return at once after a device-side EOS (see _alloc)
-        use_fao = self.fused_ao and tp == 1 and cnt is None and self.chain not in (3, 4)
-        if use_fao:
-            if torch.cuda.get_device_properties(dev).multi_processor_count < Hkv * self.NS:
-                use_fao = False                                        # the launch needs all its workgroups co-resident
-        if use_fao:
-            fao_part = Z(L, Hq * self.NS * 130, dt=torch.int64)         # per layer: partial granules [Hq][NS][130], output granules [K/2]
-            fao_x = Z(L, Hq * 64, dt=torch.int64)
-            if not hasattr(self, "fao_epoch"):
-                self.fao_epoch = torch.zeros(1, dtype=torch.int32, device=dev)
-                self.cmb_err = torch.zeros(1, dtype=torch.int32, device=dev)
-            ops.epoch_inc(self.fao_epoch, plan=plan)                    # one tag per decode step
-        cmb_gran = Z(L, Hq * 64, dt=torch.int64) if (self.cmb and not use_fao) else None      # one granule block per layer (tags cleared by the layer's attention launch)
+        cmb_gran = Z(L, Hq * 64, dt=torch.int64) if self.cmb else None      # one granule block per layer (tags cleared by the layer's attention launch)
         if self.cmb and not hasattr(self, "cmb_err"):
             self.cmb_err = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -543,13 +537,6 @@ class USDMForCausalLM:
                 h, pend = flip(h), None
             else:
                 ops.gemv(w["qkv"], h, N=nq, K=H, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, skip=skp, plan=plan)
-            if use_fao:
-                ops.attn_oproj(qkv, self.st_pos, self.cos, self.sin, self.kcache[l], self.vcache[l], w["o"], h, h, fao_part[l], fao_x[l],
-                               self.fao_epoch, self.cmb_err, Hq=Hq, Hkv=Hkv, ctx_max=self.ctx_max, NS=self.NS, scale=d ** -0.5, N=H, K=Hq * d,
-                               skip=skp, window=self.window, plan=plan)
-                ops.gemv(w["gu"], h, N=2 * I, K=H, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU, y16=act, skip=skp, plan=plan)
-                ops.gemv(w["down"], act, N=H, K=I, residual=h, y16=h, skip=skp, plan=plan)
-                continue
             use_cmb = self.cmb and tp == 1 and cnt is None and self.NS > 1 and cmb_gran is not None
             mrg = (pm, pl, po, self.NS) if ((self.merge_in_oproj or use_cmb) and cnt is None) else None
             gran = cmb_gran[l] if use_cmb else None

@@ -386,27 +386,6 @@ def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv,
     _go(plan, "usdm_attn_decode", lib.usdm_attn_decode, C_.byref(a))
 
 
-def attn_oproj(qkv, pos, cos, sin, kcache, vcache, W, residual, y16, part_gran, x_gran, epoch, err, *, Hq, Hkv, ctx_max, NS, scale,
-               N, K, skip=None, window=0, round_bf16=True, plan=None):
-    """usdm_attn_oproj: decode attention (context-split) + merge + o_proj + residual in one launch (include/usdm_hip.h)."""
-    _need_cuda(qkv, pos, cos, sin, kcache, vcache, W, residual, y16, part_gran, x_gran, epoch, err, skip)
-    if part_gran.numel() * part_gran.element_size() < Hq * NS * 130 * 8 or x_gran.numel() * x_gran.element_size() < (K // 2) * 8:
-        raise ValueError("usdm_attn_oproj: part_gran holds Hq*NS*130 and x_gran K/2 8-byte granules")
-    A = _lib.AttnOprojArgs()
-    a, g = A.attn, A.gemv
-    a.qkv, a.pos, a.Hq, a.Hkv, a.ctx_max, a.NS, a.scale = _ptr(qkv), _ptr(pos), Hq, Hkv, ctx_max, NS, scale
-    a.cos, a.sin, a.kcache, a.vcache, a.skip, a.window = _ptr(cos), _ptr(sin), _ptr(kcache), _ptr(vcache), _ptr(skip), int(window)
-    g.W, g.ldw, g.N, g.K = _ptr(W), K, N, K
-    g.round_bf16, g.residual, g.y16 = int(round_bf16), _ptr(residual), _ptr(y16)
-    A.part_gran, A.x_gran, A.epoch, A.err, A.timeout_ms = _ptr(part_gran), _ptr(x_gran), _ptr(epoch), _ptr(err), 200
-    _go(plan, "usdm_attn_oproj", lib.usdm_attn_oproj, C_.byref(A))
-
-
-def epoch_inc(epoch, plan=None):
-    _need_cuda(epoch)
-    _go(plan, "usdm_epoch_inc", lib.usdm_epoch_inc, _ptr(epoch))
-
-
 def residual_add(h, delta, n, plan=None):
     _need_cuda(h, delta)
     _go(plan, "usdm_residual_add", lib.usdm_residual_add, _ptr(h), _ptr(delta), C_.c_int32(n))
