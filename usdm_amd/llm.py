@@ -127,8 +127,10 @@ class USDMForCausalLM:
         self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
         # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
         # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
-        # shape only (4096 outputs = one 16-wave workgroup per CU).  USDM_ATTN_CMB=0 restores the combine kernel.
-        self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
+        # shape only (4096 outputs = one 16-wave workgroup per CU).  Opt-in (USDM_ATTN_CMB=1): -0.8 % per token, token-identical
+        # (profiles/r03_decode_ablation.txt 5), but the o_proj launch then carries the merge (7.7 -> 9.3 us), which would blur the
+        # per-launch weight-streaming roofline bench.py reports for usdm_gemv; the default keeps the combine kernel.
+        self.cmb = (os.environ.get("USDM_ATTN_CMB", "0") == "1" and tp_size == 1 and not self.merge_in_oproj
                     and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
         # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
         # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
@@ -141,8 +143,10 @@ class USDMForCausalLM:
         self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
         # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
         # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
-        # shape only (4096 outputs = one 16-wave workgroup per CU).  USDM_ATTN_CMB=0 restores the combine kernel.
-        self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.merge_in_oproj
+        # shape only (4096 outputs = one 16-wave workgroup per CU).  Opt-in (USDM_ATTN_CMB=1): -0.8 % per token, token-identical
+        # (profiles/r03_decode_ablation.txt 5), but the o_proj launch then carries the merge (7.7 -> 9.3 us), which would blur the
+        # per-launch weight-streaming roofline bench.py reports for usdm_gemv; the default keeps the combine kernel.
+        self.cmb = (os.environ.get("USDM_ATTN_CMB", "0") == "1" and tp_size == 1 and not self.merge_in_oproj
                     and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
         dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits
