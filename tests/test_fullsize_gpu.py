@@ -58,6 +58,34 @@ def test_config3_llm_full_width_two_layers(dev):
         assert (top2[0] - top2[1]).item() <= 2 ** -6 * top2[0].abs().item() + 1e-3
 
 
+def test_attention_combine_handoff_inside_o_proj_is_token_and_logit_identical(dev, monkeypatch):
+    """USDM_ATTN_CMB=1 (usdm_gemv cmb_gran): the 32 attention partials per head are merged by the first 32 workgroups of the o_proj
+    launch and handed to all of them as granules, instead of by the combine kernel.  Same arithmetic in the same order: 40 greedy
+    tokens AND the logits of the last step must be bit-identical to the default path, over context lengths that give empty,
+    ragged and full splits (2 full-width layers; the hand-off needs the 4096-wide 7B shape)."""
+    from oracle import mistral_oracle as MO
+    from usdm_amd.llm import USDMForCausalLM
+    cfg = dict(MO.MISTRAL_7B_USDM, num_hidden_layers=2)
+    sd = MO.random_state_dict(cfg, seed=33)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("USDM_ATTN_CMB", flag)
+        m = USDMForCausalLM.from_state_dict(sd, cfg, dev, ctx_max=512)
+        assert m.cmb == (flag == "1")
+        m.keep_logits = True
+        outs = []
+        for L0 in (9, 130, 300):
+            ids = torch.randint(0, 42003, (1, L0), generator=torch.Generator().manual_seed(L0)).to(dev)
+            o = m.generate(input_ids=ids, max_new_tokens=40)
+            outs.append((o[0].tolist(), m.last_logits.clone().cpu()))
+        res[flag] = outs
+        del m
+        torch.cuda.empty_cache()
+    for (t0, l0), (t1, l1) in zip(res["0"], res["1"]):
+        assert t0 == t1
+        assert torch.equal(l0, l1)
+
+
 def test_config4_voicebox_full_width_one_heun_step_plus_bigvgan(dev):
     """BASELINE config 4 shapes: 500 agent units + 149 prompt units -> 861 + 256 frames, full 24-layer Voicebox with CFG
     and speech prompt, Heun; n_timesteps=2 (one step, one NFE... the full 63-NFE run differs only in the loop count),
