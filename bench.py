@@ -254,17 +254,48 @@ def measure_gemv_roofline(llm):
             ms += t
             groups[f"N{key[0]}xK{key[1]}" + ("(swiglu)" if key[2] == 3 else "")] = round(t * 1e3 / len(calls), 2)
     ach = nbytes / (ms * 1e-3) / 1e9
+    # the o_proj launch of the shipped step carries the attention merge (usdm_gemv cmb_gran, llm.cmb): its kernel-only duration is
+    # part of `achieved` above as it ships; the same launch WITHOUT the merge (separate combine kernel) is timed beside it
+    oproj_plain_us = None
+    if groups is not None and llm.cmb:
+        from usdm_amd.graph import GraphedPlan
+        llm.cmb = False
+        try:
+            calls = [c for s_ in llm._build_decode() if isinstance(s_, ops.Plan) for c in s_.calls
+                     if c[0] == "usdm_gemv" and c[2][0]._obj.N == 4096 and c[2][0]._obj.K == 4096]
+        finally:
+            llm.cmb = True
+        sub = ops.Plan()
+        sub.calls = calls
+        gp = GraphedPlan(sub)
+        for _ in range(3):
+            gp.run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            gp.run()
+        e1.record()
+        torch.cuda.synchronize()
+        oproj_plain_us = round(e0.elapsed_time(e1) / 3 * 1e3 / len(calls), 2)
     traffic, traffic_src = None, None
-    try:  # PMC counters cannot be read from inside this process: use the committed rocprofv3 --pmc record of the same kernel
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_pmc.json")))
+    try:  # PMC counters cannot be read from inside this process: use the committed rocprofv3 --pmc record of the same kernel, and
+        # only if it was measured on the kernel source that is compiled now (tools/r04_profile.sh stores its sha256)
+        import hashlib
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_gemv_pmc.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "usdm_amd", "csrc", "llm_k.hip"), "rb").read()).hexdigest()
         if llm.tp_size == 1:
-            traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+            if rec.get("llm_k_hip_sha256") == sha:
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+            else:
+                traffic_src = "profiles/r04_gemv_pmc.json is stale (measured on another llm_k.hip): traffic withheld"
     except Exception:
         pass
     return {"bound": "hbm", "kernel": "gemv_kernel (usdm_gemv, 7B decode weight streaming)", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_token": n, "avg_launch_us": round(ms * 1e3 / n, 2), "avg_bytes_per_launch": int(nbytes / n),
             "algorithmic_bytes_per_token": int(nbytes), "avg_launch_us_by_shape": groups,
+            "attention_merge": ("inside the o_proj launch (usdm_gemv cmb_gran): its duration is counted as shipped" if llm.cmb else "separate combine kernel"),
+            "o_proj_launch_us_without_merge": oproj_plain_us,
             "achieved_in_eager_step": round(ach_step, 1), "avg_launch_us_in_eager_step": round(ms_step * 1e3 / n, 2),
             "method": "achieved: each GEMV shape's per-layer launches replayed back to back (hipGraph) between one HIP event pair; "
                       "achieved_in_eager_step: event pair around every launch of an eager decode step (adds event packets and launch gaps)"}
@@ -475,6 +506,8 @@ def main():
                                "Token-Voicebox 63 NFE (Heun, CFG, 3 s prompt) -> BigVGAN",
                    "wave_samples": 160000, "prompt_tokens": list(pipe.prompt_lens), "generated_tokens": pipe.n_generated,
                    "voicebox_n_timesteps": args.nt, "mel_frames": pipe.frames, "output_samples": int(audio.shape[0]),
+                   "reference_front_end": "outside the timed region (inputs per SURVEY 8d: reference_mel / reference_unit handed over; "
+                                          "sample(--reference_path) would add the prompt's tokenizer pass + get_mel, ~15-20 ms)",
                    "parallelism": f"tp{world} (LLM) + replicas", "tp_comm": pipe.tp_comm, "voicebox": pipe.vb_mode,
                    **({"shared_gpu_validation": f"{world} ranks on {torch.cuda.device_count()} GPU(s): code-path validation, not a scaling result"}
                       if os.environ.get("USDM_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count() else {})},

@@ -85,19 +85,28 @@ typedef struct usdm_gemm_args {
   int32_t split_k; int64_t c_split_stride;
   /* LayerNorm folded into the neighbouring GEMMs (post-LN block of networks.py:236-266: h1 = LN(h + attn) is consumed by the
    * feed-forward GEMM and by the next residual add, never on its own; saves the LayerNorm launch and its 22 MB round trip).
-   *   stats_out  PRODUCER (row-major plain epilogue, 128-column tiles): after bias / residual, every tile writes the sum and the
-   *              sum of squares of its 128 columns of each output row to stats_out[row][tiles_n][2] (f32; no atomics, so the
-   *              result is run-to-run reproducible).
+   *   stats_out  PRODUCER (row-major plain epilogue, 128-column tiles): after bias / residual, every tile writes the sum of its
+   *              128 columns of each output row and their M2 = sum (v - tile mean)^2 to stats_out[row][tiles_n][2] (f32; no
+   *              atomics, so the result is run-to-run reproducible).
    *   ln_mode 1  CONSUMER, A operand = the UN-normalised rows x (bf16), W = weights with gamma folded in along K:
    *              v = rstd[m] * acc[m][n] - rstd[m] * mean[m] * ln_c[n] + bias[n]   (ln_c[n] = sum_k W[n][k]; bias already holds
    *              b[n] + sum_k W0[n][k] beta[k]), i.e. exactly LN(x) W0^T + b, then the activation.  GELU bf16-out epilogue of the
    *              ping-pong tiles only.
    *   ln_mode 2  CONSUMER, residual[m][n] is UN-normalised x (f32): the residual added is LN(x)[m][n] =
    *              (x - mean[m]) * rstd[m] * ln_gamma[n] + ln_beta[n].  Row-major plain epilogue.
-   * mean / rstd come from ln_stats[row][ln_nt][2] (the producer's partial sums over ln_nt tiles of ln_C columns in all). */
+   * mean / rstd come from ln_stats[row][ln_nt][2]: per 128-column tile the producer's (sum, M2 about the tile's own mean), merged
+   * pairwise-exactly (Chan et al.) over the ln_nt tiles of ln_C = 128 * ln_nt columns: no sum(x^2) - mean^2 cancellation.
+   *   ln_guard   optional device word (ln_mode 1 and 2): OR-ed with 1 when a row has |mean| * rstd > ln_guard_ratio.  ln_mode 1
+   *              multiplies rows that were rounded to bf16 before centring, so its operand noise relative to the normalised
+   *              signal is 2^-9 * sqrt(1 + (mean / sigma)^2): the caller bounds the ratio it accepts and re-runs such inputs with
+   *              the separate LayerNorm kernel (usdm_amd/voicebox/model/networks.py does). */
   float* stats_out;
   const float* ln_stats; int32_t ln_nt, ln_mode, ln_C; float ln_eps;
   const float* ln_c; const float* ln_gamma; const float* ln_beta;
+  int32_t* ln_guard; float ln_guard_ratio;
+  /* 0: the launcher picks the tile from the shape (measured heuristics, csrc/gemm.hip); t + 1: force tile t (benchmarks and the
+   * tile-equivalence tests; the Python wrapper fills it from USDM_GEMM_TILE so the library itself reads no environment per launch) */
+  int32_t tile_sel;
 } usdm_gemm_args;
 
 int usdm_gemm(const usdm_gemm_args* args, usdm_stream_t stream);

@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ("split_k", C.c_int32), ("c_split_stride", C.c_int64),
         ("stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_nt", C.c_int32), ("ln_mode", C.c_int32), ("ln_C", C.c_int32),
         ("ln_eps", C.c_float), ("ln_c", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("ln_guard", C.c_void_p), ("ln_guard_ratio", C.c_float), ("tile_sel", C.c_int32),
     ]
 
 

@@ -29,7 +29,6 @@ namespace {
 struct GemmDev {
   usdm_gemm_args a;
   int tiles_m, tiles_n;
-  int dbg;   // USDM_GEMM_DBG (ablation switches of the ping-pong loop: 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads)
 };
 
 // compile-time loop: every accumulator index below is a constant, so nothing can fall into scratch
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4*)(sS + foB[h][j]);
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(sS + foA[h][i]);
-      if (issue && !(g.dbg & 1)) pp_issue(slotn, sn, h, chk);
+      if (issue) pp_issue(slotn, sn, h, chk);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (wait_n > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
       else if (wait_n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -435,13 +434,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if (!(g.dbg & 2))
-        static_for<TM>([&](auto I) {
-          static_for<TN>([&](auto J) {
-            acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
-                                                                acc[I][J], 0, 0, 0);
-          });
+      static_for<TM>([&](auto I) {
+        static_for<TN>([&](auto J) {
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
+                                                              acc[I][J], 0, 0, 0);
         });
+      });
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -539,18 +537,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     // the K loop (in the prologue the loads' wait would sit in front of the first K-step): the latency runs under the accumulator
     // dump below, and the barrier that follows the dump publishes rowst.
     if (a.ln_mode) {
+      // per-tile statistics are (sum, M2 about the tile's own mean) of ln_C / ln_nt columns each: merged as Chan et al. do, so the
+      // variance never goes through sum(x^2) - mean^2 (which loses |mean| / sigma squared in relative accuracy)
+      const float ncol = (float)(a.ln_C / a.ln_nt), inv_ncol = 1.0f / ncol;
+      bool unsafe = false;
       for (int i = tid; i < BM; i += NTH) {
         const int m = m0 + i;
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, m2 = 0.f;
+        float mean = 0.f;
         if (m < a.M) {
           const float2* sp = (const float2*)a.ln_stats + ((int64_t)bz * a.c_bstride + m) * a.ln_nt;
-          for (int t = 0; t < a.ln_nt; ++t) { const float2 v = sp[t]; s1 += v.x; s2 += v.y; }
+          for (int t = 0; t < a.ln_nt; ++t) s1 += sp[t].x;
+          mean = s1 / (float)a.ln_C;
+          for (int t = 0; t < a.ln_nt; ++t) { const float2 v = sp[t]; const float d = v.x * inv_ncol - mean; m2 += v.y + ncol * d * d; }
         }
-        const float mean = s1 / (float)a.ln_C;
-        const float var = fmaxf(s2 / (float)a.ln_C - mean * mean, 0.f);
+        const float var = m2 / (float)a.ln_C;
         const float rstd = rsqrtf(var + a.ln_eps);
         rowst[2 * i] = rstd; rowst[2 * i + 1] = rstd * mean;
+        // ln_mode 1 multiplies rows that were rounded to bf16 BEFORE centring: the operand's rounding noise relative to the
+        // normalised signal grows with |mean| / sigma.  Rows beyond the caller's bound are reported, never silently accepted.
+        if (a.ln_guard && m < a.M && fabsf(mean) * rstd > a.ln_guard_ratio) unsafe = true;
       }
+      if (a.ln_guard && tn == 0 && unsafe) atomicOr(a.ln_guard, 1);
     }
   }
   float* ct = (float*)smem;  // [BM][CST] f32, or [BN][CSTT] in transposed mode
@@ -872,8 +880,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           }
         }
         if (stp) {   // the C4 threads that share this row are one half (BN = 128) or one DPP row (BN = 64) of a wave: reduce, one 8-byte store per row and tile
-          const float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          // (sum, M2 about the tile mean) of this tile's BN columns of the row: two dependent lane reductions instead of one,
+          // but no sum of raw squares (see the consumer)
+          const float t1 = (v[0] + v[1]) + (v[2] + v[3]);
           const float s1 = C4 == 32 ? half_sum(t1) : row16_sum(t1);
+          const float mt = s1 * (1.0f / (float)BN);
+          const float d0 = v[0] - mt, d1 = v[1] - mt, d2 = v[2] - mt, d3 = v[3] - mt;
+          const float t2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
           const float s2 = C4 == 32 ? half_sum(t2) : row16_sum(t2);
           if ((tid & (C4 - 1)) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
         }
@@ -920,8 +933,6 @@ int launch(const usdm_gemm_args& a, hipStream_t st) {
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
-  static const int dbg = getenv("USDM_GEMM_DBG") ? atoi(getenv("USDM_GEMM_DBG")) : 0;
-  g.dbg = dbg;
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1));
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH, PP>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
@@ -978,8 +989,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   const int64_t t12864 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) * z;
   int sel;  // 0-2: register-staged 128x128 / 128x64 / 64x64; 4-6: the same tiles with 2-stage LDS-DMA; 7-11: deeper DMA pipelines; 12-13: ping-pong
   // Single-tap GEMMs (Linear layers): chosen from tools/vb_gemm_bench.py (the Voicebox layer's GEMMs over cold weights) and
-  // tools/bench_gemm_tiles.py, see profiles/r01_gemm_ablation.txt.  USDM_GEMM_HEUR=0 restores the register-staged choice.
-  static const int heur = getenv("USDM_GEMM_HEUR") ? atoi(getenv("USDM_GEMM_HEUR")) : 1;
+  // tools/bench_gemm_tiles.py, see profiles/r01_gemm_ablation.txt.
+  constexpr int heur = 1;
   // Big single-tap bf16 GEMMs: the 8-wave ping-pong tiles (256x128, or 288x128 when that saves a round of workgroups) at one
   // workgroup per CU, 1.2-2x the 128x128 tile on the Voicebox and LLM-prefill shapes (profiles/r02_gemm_ablation.txt section 4)
   const int64_t t12 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 128) * z, t13 = (int64_t)cdiv(a.M, 288) * cdiv(a.N, 128) * z;
@@ -988,8 +999,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
                      (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
   // ... and its 128x128 form where the big tiles would leave half the CUs idle (96-256 tiles of 128x128, one per CU)
   const int64_t t14 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
-  static const int pp14 = getenv("USDM_GEMM_PP_SMALL") ? atoi(getenv("USDM_GEMM_PP_SMALL")) : 1;
-  const bool pp_small = pp14 && heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 &&   // (K-concatenated sources included: the skip Linear 31.1 -> 25.7 us, r03_vb_ablation.txt 8)
+  const bool pp_small = heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 &&   // (K-concatenated sources included: the skip Linear 31.1 -> 25.7 us, r03_vb_ablation.txt 8)
                         t12 < 128 && t14 >= 96 && t14 <= 256 &&
                         a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256;
   if (pp_small) sel = 14;
@@ -1011,7 +1021,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
-  if (const char* ov = getenv("USDM_GEMM_TILE")) sel = atoi(ov);  // benchmarking override
+  if (a.tile_sel > 0) sel = a.tile_sel - 1;   // benchmarking / test override (usdm_gemm_args.tile_sel; ops.gemm fills it from USDM_GEMM_TILE)
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tile has row-major epilogues only
   if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
@@ -1019,7 +1029,9 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
                        a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
                    "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
     USDM_CHECK_ARG(!a.stats_out || (a.act == USDM_ACT_NONE && a.split_k <= 1), "usdm_gemm: stats_out needs a plain, unsplit epilogue");
-    USDM_CHECK_ARG(a.ln_mode == 0 || (a.ln_stats && a.ln_nt > 0 && a.ln_nt <= 64 && a.ln_C > 0), "usdm_gemm: ln_stats / ln_nt / ln_C");
+    USDM_CHECK_ARG(a.ln_mode == 0 || (a.ln_stats && a.ln_nt > 0 && a.ln_nt <= 64 && a.ln_C > 0 && a.ln_C == a.ln_nt * 128),
+                   "usdm_gemm: ln_stats / ln_nt / ln_C (the producer's tiles are 128 columns wide)");
+    USDM_CHECK_ARG(!a.ln_guard || a.ln_guard_ratio > 0.f, "usdm_gemm: ln_guard needs ln_guard_ratio > 0");
     USDM_CHECK_ARG(a.ln_mode != 1 || (a.ln_c && a.act == USDM_ACT_GELU && a.C16 && !a.C32 && !a.residual && a.alpha == 1.0f && a.split_k <= 1),
                    "usdm_gemm: ln_mode 1 is the GELU bf16-out epilogue (no residual, alpha 1)");
     USDM_CHECK_ARG(a.ln_mode != 2 || (a.ln_gamma && a.ln_beta && a.residual && a.res_dtype == USDM_F32 && a.act == USDM_ACT_NONE && (a.ldr & 3) == 0),

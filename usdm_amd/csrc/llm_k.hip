@@ -517,11 +517,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
   const int bi = blockIdx.z;                      // sequence of a batched decode step (0 when single)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = a.pos[bi];
-  if ((unsigned)pos >= (unsigned)a.ctx_max) return;   // never append past the cache / rope table (a caller bug: the host bounds every sequence)
-  if (a.cmb_gran) {   // clear the tags of the o_proj hand-off granules (usdm_gemv cmb_gran) for the launch that follows
+  if (a.cmb_gran) {   // clear the tags of the o_proj hand-off granules (usdm_gemv cmb_gran) for the launch that follows.  BEFORE the
+    // position check below: on that (caller-bug) path the o_proj launch must not find the previous token's granules still tagged
     const int gi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 256 + tid;
     if (bi == 0 && gi < a.Hq * 64) a.cmb_gran[gi] = 0ull;
   }
+  if ((unsigned)pos >= (unsigned)a.ctx_max) return;   // never append past the cache / rope table (a caller bug: the host bounds every sequence)
   const int ctx = pos + 1;
   const int lo = (a.window > 0 && ctx > a.window) ? ctx - a.window : 0;   // sliding window: keys lo .. pos
   const int chunk = (ctx - lo + NS - 1) / NS;

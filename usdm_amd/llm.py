@@ -125,28 +125,12 @@ class USDMForCausalLM:
         # wants make the latency-bound split kernel slower (rank-0-of-8 proxy: 1.10 -> 1.23 ms/token).  USDM_ATTN_MERGE_IN_OPROJ=1
         # enables it.
         self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
-        # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
-        # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
-        # shape only (4096 outputs = one 16-wave workgroup per CU).  Opt-in (USDM_ATTN_CMB=1): -0.8 % per token, token-identical
-        # (profiles/r03_decode_ablation.txt 5), but the o_proj launch then carries the merge (7.7 -> 9.3 us), which would blur the
-        # per-launch weight-streaming roofline bench.py reports for usdm_gemv; the default keeps the combine kernel.
-        self.cmb = (os.environ.get("USDM_ATTN_CMB", "0") == "1" and tp_size == 1 and not self.merge_in_oproj
-                    and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
-        # Decode attention is split over the context (NS workgroups per kv head).  The NS partials per head are merged in the
-        # o_proj GEMV's x-staging prologue (usdm_gemv mrg_*; no combine launch) -> few, fat splits: every o_proj workgroup reads
-        # all of them (NS x 16 KB from L2).  USDM_ATTN_MERGE_IN_OPROJ=0 restores the separate combine kernel (NS = 32).
-        # Measured (profiles/r02_decode_ablation.txt) and OFF by default: on the single-GPU 7B shapes the merge costs the o_proj
-        # launch more than the combine launch it removes (2.97 -> 3.10 ms/token at NS = 8: 128 KB of partials per workgroup and
-        # two dependent L2 round trips no longer hide under the weight ring; NS = 32: 3.28), and the fewer, fatter splits it
-        # wants make the latency-bound split kernel slower (rank-0-of-8 proxy: 1.10 -> 1.23 ms/token).  USDM_ATTN_MERGE_IN_OPROJ=1
-        # enables it.
-        self.merge_in_oproj = os.environ.get("USDM_ATTN_MERGE_IN_OPROJ", "0") == "1"
-        # Hand-off form (round 3, usdm_gemv cmb_gran): no combine launch either, but the merge is done ONCE per head by the o_proj
-        # launch's first 32 workgroups and handed to the others as granules, under the launch's first weight ring.  Single-GPU 7B
-        # shape only (4096 outputs = one 16-wave workgroup per CU).  Opt-in (USDM_ATTN_CMB=1): -0.8 % per token, token-identical
-        # (profiles/r03_decode_ablation.txt 5), but the o_proj launch then carries the merge (7.7 -> 9.3 us), which would blur the
-        # per-launch weight-streaming roofline bench.py reports for usdm_gemv; the default keeps the combine kernel.
-        self.cmb = (os.environ.get("USDM_ATTN_CMB", "0") == "1" and tp_size == 1 and not self.merge_in_oproj
+        # Hand-off form (round 3, usdm_gemv cmb_gran; the DEFAULT since round 4): no combine launch either, but the merge is done ONCE
+        # per head by the o_proj launch's first 32 workgroups and handed to the others as granules, under the launch's first weight
+        # ring.  Single-GPU 7B shape only (4096 outputs = one 16-wave workgroup per CU).  -0.8 % per token, token- and logit-identical
+        # (profiles/r03_decode_ablation.txt 5, tests/test_fullsize_gpu.py).  The o_proj launch then carries the merge (7.7 -> 9.3 us);
+        # bench.py's roofline object reports that launch both ways.  USDM_ATTN_CMB=0 restores the separate combine kernel.
+        self.cmb = (os.environ.get("USDM_ATTN_CMB", "1") == "1" and tp_size == 1 and not self.tp_path and not self.merge_in_oproj
                     and c["hidden_size"] == 4096 and self.Hq * c["head_dim"] == 4096)
         dflt = max(8, -(-self.ctx_max // 512)) if self.merge_in_oproj else 32
         self.NS = int(os.environ.get("USDM_DECODE_SPLITS", str(dflt))) if decode_splits is None else decode_splits

@@ -4,6 +4,7 @@ These exist for the parity tests and for the Python drop-ins; they add no arithm
 """
 import ctypes as C
 import ctypes as C_
+import os
 
 import torch
 
@@ -99,6 +100,12 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
         _need_cuda(ln["stats"], ln.get("c"), ln.get("gamma"), ln.get("beta"))
         a.ln_stats, a.ln_nt, a.ln_mode, a.ln_C, a.ln_eps = _ptr(ln["stats"]), ln["nt"], ln["mode"], ln["C"], ln.get("eps", 1e-5)
         a.ln_c, a.ln_gamma, a.ln_beta = _ptr(ln.get("c")), _ptr(ln.get("gamma")), _ptr(ln.get("beta"))
+        if ln.get("guard") is not None:      # device word OR-ed with 1 when a row's |mean| / sigma exceeds guard_ratio
+            _need_cuda(ln["guard"])
+            a.ln_guard, a.ln_guard_ratio = _ptr(ln["guard"]), float(ln["guard_ratio"])
+    tile = os.environ.get("USDM_GEMM_TILE")      # benchmarks / tile-equivalence tests: the library itself reads no environment
+    if tile is not None:
+        a.tile_sel = int(tile) + 1
     if qkv is not None:
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]

@@ -63,6 +63,7 @@ class CFM(BaseModule):
             noise = (torch.stack(list(noise)) if not torch.is_tensor(noise) else noise).to(dev, torch.float32).contiguous()
             if noise.shape != (n_noise, B, F_, S):
                 raise ValueError(f"noise must have shape {(n_noise, B, F_, S)}, got {tuple(noise.shape)}")
+        noise_in = noise
         cfg = gradient_scale > 0
         # One plan / hipGraph / workspace per BUCKET of lengths (Transformer.bucket_frames): the state, the noise and the
         # condition are zero-padded to the bucket's frame count Sb and the true lengths go to the kernels through kv_len.
@@ -149,6 +150,21 @@ class CFM(BaseModule):
                                    z_commit=Z, t_next=float(t), **common)
             if not last:
                 dt = t_span[steps + 1] - t
+        # Folded LayerNorm guard (networks.LN_GUARD_RATIO): an input that left the fold's accuracy bound switches the fold off and the
+        # whole solve is repeated on the LayerNorm-kernel plan with the same draws.  A CFG pair decides together.
+        tripped = self.estimator.ln_guard_tripped()
+        if split:
+            flags = torch.zeros(2, device=dev, dtype=torch.float32)
+            gather(flags, torch.full((1,), float(tripped), device=dev))
+            tripped = bool(flags.sum().item() > 0)
+            if tripped:                      # the partner's half tripped it: same decision on both ranks
+                self.estimator.ln_fold_ok = False
+                self.estimator._plans.clear()
+        if tripped:
+            if trace is not None:
+                del trace[:]
+            return self.generate(x, cond, cond_lengths, n_timesteps, solver=solver, gradient_scale=gradient_scale, speech_prompt=speech_prompt,
+                                 prompt_lengths=prompt_lengths, noise=noise_in, trace=trace, cfg_group=cfg_group)
         return Z[:, :, :S_true].contiguous() if S_true != S else Z
 
 
