@@ -290,13 +290,22 @@ int usdm_gemv_nblocks(int32_t N, int32_t act); /* number of partials the lm_head
 
 int usdm_gemv_threads(const usdm_gemv_args* args);   /* threads per workgroup usdm_gemv would launch this projection with */
 
-/* Batched decode: the same GEMV over nb <= 4 input vectors, weights streamed once per step.
- * g holds item 0's pointers; item b is at + b * stride.  Per item the arithmetic is that of usdm_gemv, bit for bit. */
+/* Batched decode (the serving path's request lists, src/inference_vllm.py:109-125): the same projection over nb
+ * input vectors, weights streamed ONCE per step.  g holds item 0's pointers; item b is at + b * stride.  Two forms:
+ *   VALU (nb <= 4)          v_dot2 per sequence; per item the arithmetic of usdm_gemv, bit for bit.
+ *   matrix cores (nb <= 16) the weights as the A operand of v_mfma_f32_16x16x32_bf16 (16 rows x 32 K per instruction, loaded from
+ *                           HBM straight into the fragment layout), the nb activation vectors as B: the step costs what the batch-1
+ *                           step costs in HBM time for any nb <= 16.  Same rounding points (RMSNorm, bf16 outputs, SwiGLU,
+ *                           residual, bf16 logits), but K is summed in a different order than usdm_gemv: equal to f32 rounding of
+ *                           the accumulation, not bit for bit (csrc/llm_mfma_k.hip).
+ * form: 0 = VALU for nb <= 4, matrix cores above; 1 = matrix cores; -1 = VALU (nb <= 4 only). */
 typedef struct usdm_gemv_batch_args {
   usdm_gemv_args g;          /* x_delta / x_out must be NULL */
   int32_t nb;
   int64_t x_bs, y_bs, res_bs; /* element strides between items of x, y16 / y32, residual */
-  int32_t part_bs;            /* element stride between items of part_val / part_idx (>= usdm_gemv_nblocks) */
+  int32_t part_bs;            /* element stride between items of part_val / part_idx (>= usdm_gemv_nblocks; the matrix-core form
+                                 writes one partial per workgroup (<= 256) and fills the rest with "no candidate") */
+  int32_t form;
 } usdm_gemv_batch_args;
 int usdm_gemv_batch(const usdm_gemv_batch_args* args, usdm_stream_t stream);
 

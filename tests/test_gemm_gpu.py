@@ -336,9 +336,10 @@ def test_ksplit_pingpong_tiles(dev, tile, tile_env):
         return f()
 
     def close(x, y, what):
-        if x.dtype == torch.bfloat16:
-            ulp = (x.view(torch.int16).int() - y.view(torch.int16).int()).abs().max().item()
-            assert ulp <= 1, f"{what}: {ulp} bf16 ulps"
+        if x.dtype == torch.bfloat16:       # one bf16 ulp of the larger magnitude, plus the f32 accumulation difference near zero
+            xf, yf = x.float(), y.float()
+            tol = 2.0 ** -7 * torch.maximum(xf.abs(), yf.abs()) + 1e-5 * xf.abs().max()
+            assert bool(((xf - yf).abs() <= tol).all()), f"{what}: bf16 outputs differ by more than an ulp"
         else:
             m = torch.isfinite(x)
             assert torch.equal(m, torch.isfinite(y)), f"{what}: written elements differ"

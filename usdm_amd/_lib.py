@@ -127,6 +127,7 @@ class GemvChainArgs(C.Structure):
 class GemvBatchArgs(C.Structure):
     _fields_ = [
         ("g", GemvArgs), ("nb", C.c_int32), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("res_bs", C.c_int64), ("part_bs", C.c_int32),
+        ("form", C.c_int32),
     ]
 
 

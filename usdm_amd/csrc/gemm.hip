@@ -29,6 +29,7 @@ namespace {
 struct GemmDev {
   usdm_gemm_args a;
   int tiles_m, tiles_n;
+  int abl;   // usdm_gemm_args.tile_sel bits 8..: ablation switches of the K-split ping-pong loop for tools/ (1 no in-loop DMA, 2 no MFMA, 4 no fragment reads)
 };
 
 // compile-time loop: every accumulator index below is a constant, so nothing can fall into scratch
@@ -445,11 +446,13 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
       const char* sA = smem + slot * STAGE + fbaseA;
       const char* sK = smem + slot * STAGE + fbaseK;
       const char* sSn = smem + slot * STAGE + fbaseS;
+      if (!(g.abl & 4)) {
 #pragma unroll
-      for (int j = 0; j < TN / 2; ++j) { fb[j] = *(const u32x4*)(sK + j * 2048); fb[j + TN / 2] = *(const u32x4*)(sSn + j * 2048); }
+        for (int j = 0; j < TN / 2; ++j) { fb[j] = *(const u32x4*)(sK + j * 2048); fb[j + TN / 2] = *(const u32x4*)(sSn + j * 2048); }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(sA + i * 2048);
-      if (issue) pp_issue(slotn, sn, 2, chk);
+        for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(sA + i * 2048);
+      }
+      if (issue && !(g.abl & 1)) pp_issue(slotn, sn, 2, chk);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (wait_n > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
       else if (wait_n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (!(g.abl & 2))
       static_for<TM>([&](auto I) {
         static_for<TN>([&](auto J) {
           acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
@@ -1055,6 +1059,7 @@ int launch(const usdm_gemm_args& a, hipStream_t st) {
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
+  g.abl = a.tile_sel > 0 ? (a.tile_sel >> 8) : 0;
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1));
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH, PP, KSP>), grid, dim3(NWM * NWN * 64 * (KSP ? 2 : 1)), 0, st, g);
   USDM_LAUNCH_CHECK();
@@ -1143,7 +1148,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
   else if (a.N >= 4096 && t12864 >= 448) sel = 1;
   else sel = 2;
-  if (a.tile_sel > 0) sel = a.tile_sel - 1;   // benchmarking / test override (usdm_gemm_args.tile_sel; ops.gemm fills it from USDM_GEMM_TILE)
+  if (a.tile_sel > 0) sel = (a.tile_sel & 0xff) - 1;   // benchmarking / test override (usdm_gemm_args.tile_sel; ops.gemm fills it from USDM_GEMM_TILE)
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tiles have row-major epilogues only
   if (sel == 16 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 15;

@@ -281,10 +281,16 @@ int launch_nb(const usdm_gemv_batch_args& ba, hipStream_t st) {
 }
 }  // namespace
 
+int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st);   // llm_mfma_k.hip: the matrix-core form, 1..16 sequences
+
 extern "C" int usdm_gemv_batch(const usdm_gemv_batch_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(pa && pa->g.W && pa->g.x, "usdm_gemv_batch: null args");
   const usdm_gemv_args& a = pa->g;
-  USDM_CHECK_ARG(pa->nb >= 1 && pa->nb <= 4, "usdm_gemv_batch: 1..4 sequences per step");
+  USDM_CHECK_ARG(pa->g.N > 0 && pa->g.K > 0, "usdm_gemv_batch: bad N/K");
+  USDM_CHECK_ARG(a.y16 || a.y32 || a.part_val, "usdm_gemv_batch: no output");
+  USDM_CHECK_ARG(!a.x_delta && !a.x_out, "usdm_gemv_batch: x_delta / x_out are batch-1 (tensor-parallel) only");
+  if (pa->form == 1 || (pa->form == 0 && pa->nb > 4)) return usdm_gemv_mfma_launch(pa, (hipStream_t)stream);
+  USDM_CHECK_ARG(pa->nb >= 1 && pa->nb <= 4, "usdm_gemv_batch: the VALU form takes 1..4 sequences per step (form = 1 or nb > 4: matrix cores, <= 16)");
   USDM_CHECK_ARG(a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "usdm_gemv_batch: bad N/K/ldw");
   USDM_CHECK_ARG(a.K <= 16384, "usdm_gemv_batch: K too large for the LDS-resident input vectors");
   const bool glu = a.act == USDM_ACT_SWIGLU;

@@ -637,16 +637,21 @@ class USDMForCausalLM:
         plan.hold(st)
         return plan
 
+    MAX_BATCH = 16      # sequences per decode step (usdm_gemv_batch: VALU form up to 4, matrix-core form up to 16)
+
     @torch.no_grad()
-    def generate_batch(self, input_ids_list, max_new_tokens, bad_words_ids=None, eos_token_id=None, min_new_tokens=0):
-        """Greedy generation of several utterances in lockstep (the serving-side batching of inference_vllm.py:109-125, here
-        for up to 4 sequences per step; longer lists run in groups).  Each prompt is prefilled on its own; every decode
-        step then streams the weights once for the whole group.  Per sequence the result equals generate()'s."""
+    def generate_batch(self, input_ids_list, max_new_tokens, bad_words_ids=None, eos_token_id=None, min_new_tokens=0, group=None):
+        """Greedy generation of several utterances in lockstep (the serving-side batching of inference_vllm.py:109-125): up to
+        `group` (default 16) sequences per step, longer lists run in groups.  Each prompt is prefilled on its own; every decode
+        step then streams the weights once for the whole group.  Groups of <= 4 run on the VALU kernel and equal generate() per
+        sequence bit for bit; larger groups run on the matrix cores (usdm_gemv_batch form 1): the same rounding points, K summed
+        in another order - equal to the oracle up to its near-ties, not bit-identical with generate()."""
         if self.tp_path:
             raise NotImplementedError("batched decode is single-GPU")
+        group = self.MAX_BATCH if group is None else max(1, min(int(group), self.MAX_BATCH))
         outs = []
-        for g0 in range(0, len(input_ids_list), 4):
-            outs += self._generate_group(input_ids_list[g0:g0 + 4], max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens)
+        for g0 in range(0, len(input_ids_list), group):
+            outs += self._generate_group(input_ids_list[g0:g0 + group], max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens)
         return outs
 
     def _generate_group(self, ids_list, max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens):

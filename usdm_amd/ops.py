@@ -105,7 +105,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
             a.ln_guard, a.ln_guard_ratio = _ptr(ln["guard"]), float(ln["guard_ratio"])
     tile = os.environ.get("USDM_GEMM_TILE")      # benchmarks / tile-equivalence tests: the library itself reads no environment
     if tile is not None:
-        a.tile_sel = int(tile) + 1
+        a.tile_sel = int(tile) + 1 + (int(os.environ.get("USDM_GEMM_ABL", "0")) << 8)      # (ablation switches of the K-split loop, tools/ only)
     if qkv is not None:
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]
@@ -361,8 +361,9 @@ def rope_cache(qkv, cos, sin, kcache, vcache, *, ld, S, pos0, Hq, Hkv, ctx_max, 
 
 
 def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
-               residual=None, y16=None, y32=None, ban=None, part_val=None, part_idx=None, idx_offset=0, plan=None):
-    """usdm_gemv_batch: the decode GEMV over nb <= 4 input vectors (x is [nb][x_bs], outputs [nb][y_bs])."""
+               residual=None, y16=None, y32=None, ban=None, part_val=None, part_idx=None, idx_offset=0, form=0, plan=None):
+    """usdm_gemv_batch: the decode projection over nb <= 16 input vectors (x is [nb][x_bs], outputs [nb][y_bs]).
+    form 0: VALU kernel for nb <= 4, matrix-core kernel above; 1: matrix cores; -1: VALU."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx)
     b = GemvBatchArgs()
     a = b.g
@@ -371,7 +372,7 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
     a.act, a.round_bf16 = act, int(round_bf16)
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
-    b.nb, b.x_bs, b.y_bs, b.res_bs, b.part_bs = nb, x_bs, y_bs, res_bs, part_bs
+    b.nb, b.x_bs, b.y_bs, b.res_bs, b.part_bs, b.form = nb, x_bs, y_bs, res_bs, part_bs, form
     _go(plan, "usdm_gemv_batch", lib.usdm_gemv_batch, C_.byref(b))
 
 

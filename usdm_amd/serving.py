@@ -8,8 +8,8 @@ How requests are executed
     are recognised by probing and turned into the device-side ban mask: banned lm_head rows are not even streamed, and the
     decode step stays one hipGraph;
   * several requests that share a mask - greedy (top_k = 1 / temperature = 0, what the reference passes) AND sampled - are served by
-    CONTINUOUS BATCHING over the 4 sequence slots of the batched decode (usdm_gemv_batch: the weights are streamed once per step
-    for all slots): a finished sequence's slot is refilled from the queue at the next scheduling point (every 8 steps) while
+    CONTINUOUS BATCHING over the 16 sequence slots of the batched decode (usdm_gemv_batch: the weights are streamed once per step
+    for all slots; 4 slots for groups of <= 4 requests): a finished sequence's slot is refilled from the queue at the next scheduling point (every 8 steps) while
     the other slots keep decoding.  Sampling state is PER SLOT (usdm_sample_final's batched form: every slot has its own
     temperature / top-k / top-p / seed block on the device and its own Philox counter), so a request sampled inside a batch
     returns exactly the tokens it returns alone; a greedy request in a sampled batch carries top_k = 1;
@@ -25,7 +25,8 @@ import torch
 
 from .graph import GraphedPlan
 
-MAX_SLOTS = 4       # usdm_gemv_batch streams the weights once for up to 4 input vectors
+MAX_SLOTS = 16      # usdm_gemv_batch streams the weights once per step for up to 16 sequences (matrix-core form above 4)
+SMALL_SLOTS = 4     # groups of <= 4 requests use the 4-slot plan (VALU form: per slot bit-identical with the single-request path)
 CHUNK = 8           # decode steps between two scheduling points (host sync: stop checks, slot turnover)
 
 
@@ -223,24 +224,25 @@ class LLM:
         why = "stop" if (toks and toks[-1] in r["stops"] and len(toks) >= sp.min_tokens) else "length"
         return toks, why
 
-    # ------------------------------------------------------------------ continuous batching over the 4 decode slots
+    # ------------------------------------------------------------------ continuous batching over the decode slots
     def _run_batched(self, grp):
         llm = self.llm
         from . import ops
-        bb = llm._batch_buffers(MAX_SLOTS)
+        nslots = SMALL_SLOTS if len(grp) <= SMALL_SLOTS else MAX_SLOTS
+        bb = llm._batch_buffers(nslots)
         sampled = any(not r["sp"].greedy for r in grp)       # one sampled request -> the whole group runs on the sampling graph
         key = "decode_sampled" if sampled else "decode"
         if bb[key] is None:
-            bb[key] = GraphedPlan(llm._build_decode_batch(MAX_SLOTS, sampling=sampled))
+            bb[key] = GraphedPlan(llm._build_decode_batch(nslots, sampling=sampled))
         decode = bb[key]
         self.stats["sampled_in_batch"] = self.stats.get("sampled_in_batch", 0) + sum(not r["sp"].greedy for r in grp)
-        for b in range(MAX_SLOTS):                               # idle slots: harmless greedy knobs
+        for b in range(nslots):                               # idle slots: harmless greedy knobs
             ops.set_sample_params(bb["sp"][b], 1.0, 1, 1.0, 0)
         llm.ban.copy_(grp[0]["mask"][llm.v0:llm.v1])
-        queue, slots, results = deque(grp), [None] * MAX_SLOTS, []
+        queue, slots, results = deque(grp), [None] * nslots, []
         self.stats["batched_requests"] += len(grp)
         while queue or any(s is not None for s in slots):
-            for b in range(MAX_SLOTS):                               # admit: prefill the prompt into the free slot's cache
+            for b in range(nslots):                               # admit: prefill the prompt into the free slot's cache
                 if slots[b] is None and queue:
                     r = queue.popleft()
                     L = len(r["ids"])
@@ -257,9 +259,9 @@ class LLM:
                     llm._run_segs(segs)                               # (+ first token)
                     slots[b] = dict(r=r, produced=1)
                     self.stats["admissions"] += 1
-            active = [b for b in range(MAX_SLOTS) if slots[b] is not None]
+            active = [b for b in range(nslots) if slots[b] is not None]
             self.stats["max_active"] = max(self.stats["max_active"], len(active))
-            for b in range(MAX_SLOTS):                               # idle slots decode garbage into row 0 of their own cache
+            for b in range(nslots):                               # idle slots decode garbage into row 0 of their own cache
                 if slots[b] is None:
                     bb["step"][b] = 0
                     bb["pos"][b] = 0
@@ -279,7 +281,7 @@ class LLM:
                     need = max(need, 1)
             if not need or (freed and queue):
                 continue                                             # refill the freed slot(s) before spending more steps
-            live = [b for b in range(MAX_SLOTS) if slots[b] is not None]
+            live = [b for b in range(nslots) if slots[b] is not None]
             # never more steps than the slot with the FEWEST tokens left: batch slots have no device-side `done` word, so a
             # slot would otherwise keep decoding to the end of the chunk - past its max_new, and for a request that runs to the
             # context limit (the reference passes max_tokens = model_max_length) past ctx_max, i.e. into the next head's / the
