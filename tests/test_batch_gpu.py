@@ -90,10 +90,14 @@ def test_generate_batch_vs_oracle(dev, group):
     assert len(refs[1][0]) <= 17 + 10
 
 
-def _close_bf16(y, ref, what):
-    """within one bf16 ulp of the larger magnitude (+ the f32 accumulation difference near zero)"""
+def _close_bf16(y, ref, what, ulps=1, mag=None):
+    """within `ulps` bf16 ulps of the larger magnitude (+ the f32 accumulation difference near zero); mag: magnitude of a term that
+    was added after a rounding (the residual: an ulp of the rounded product can be many ulps of a sum that cancels)"""
     yf, rf = y.float(), ref.float()
-    tol = 2.0 ** -7 * torch.maximum(yf.abs(), rf.abs()) + 2e-5 * rf.abs().max()
+    m = torch.maximum(yf.abs(), rf.abs())
+    if mag is not None:
+        m = torch.maximum(m, mag.float().abs().to(m.device))
+    tol = ulps * 2.0 ** -7 * m + 2e-5 * rf.abs().max()
     bad = (yf - rf).abs() > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} outputs beyond one bf16 ulp, max diff {(yf - rf).abs().max().item()}"
 
@@ -119,7 +123,7 @@ def test_gemv_batch_matrix_core_form(dev, N, K, act, norm, res, nb):
     for b in range(nb):
         y = torch.zeros(nout, dtype=bf, device=dev)
         ops.gemv(W, X[b], N=N, K=K, norm_w=g, act=act, residual=R[b] if res else None, y16=y)
-        _close_bf16(Yb[b], y, f"item {b} vs usdm_gemv")
+        _close_bf16(Yb[b], y, f"item {b} vs usdm_gemv", ulps=3 if act == 3 else (2 if res else 1), mag=R[b] if res else None)   # SwiGLU: three chained roundings
     # float64 with the same rounding points
     x = X.double().cpu()
     if norm:
@@ -133,7 +137,7 @@ def test_gemv_batch_matrix_core_form(dev, N, K, act, norm, res, nb):
         ref = acc.to(bf)
         if res:
             ref = (ref.double() + R.double().cpu()).to(bf)
-    _close_bf16(Yb.cpu(), ref, "vs float64")
+    _close_bf16(Yb.cpu(), ref, "vs float64", ulps=3 if act == 3 else (2 if res else 1), mag=R.cpu() if res else None)
 
 
 @pytest.mark.parametrize("nb", [3, 16])
@@ -159,7 +163,7 @@ def test_gemv_batch_matrix_core_lm_head(dev, nb):
         ops.gemv(W, X[b], N=V, K=K, norm_w=g, ban=ban, part_val=pv1, part_idx=pi1, y32=l1)
         ok = ~banned
         _close_bf16(lg[b].cpu()[ok].to(bf), l1.cpu()[ok].to(bf), f"logits of item {b}")
-        best = int(pi[b][pv[b].argmax()].item())
+        best = int(pi[b][pv[b] == pv[b].max()].min().item())       # usdm_argmax_final's rule: ties between partials -> lowest id
         row = lg[b].cpu()
         assert row[best] == row.max() and best == int((row == row.max()).nonzero()[0]), "partials do not hold the lowest-id arg-max of the logits written"
 

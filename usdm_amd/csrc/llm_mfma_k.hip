@@ -11,8 +11,8 @@
 // the B operand (lane (b, g) holds x[b][k0 + 8 g .. + 8)).  D[row][sequence]: lane (b, g) ends with 4 consecutive output features
 // of sequence b.  No LDS on the weight path, no transposes.
 //
-// Decomposition: ONE 16-wave workgroup per CU; the 16 waves split K (wave w owns K chunks [w cpw, (w + 1) cpw) of 32), so the
-// activation slice a wave needs is 8 fragments that it HOLDS in registers for every tile (K <= 4096: all RMSNorm-fed projections and
+// Decomposition: ONE 8-wave workgroup per CU; the 8 waves split K (wave w owns K chunks [w cpw, (w + 1) cpw) of 32), so the
+// activation slice a wave needs is 16 fragments that it HOLDS in registers for every tile (K <= 4096: all RMSNorm-fed projections and
 // o_proj; the RMSNorm with HF's rounding points is applied to the held fragments in the prologue, under the first weight loads), or
 // streams beside the weights (down_proj, K = 14336, one tile per workgroup).  Tiles (16 rows; 12 where that balances the 256 CUs
 // better; SwiGLU: 8 gate + 8 up rows of the same 8 features) are dealt round-robin to the workgroups; a wave keeps the loads of two
@@ -24,33 +24,57 @@
 // (tests/test_batch_gpu.py: near-tie rule), not against the batch-1 kernel.
 #include "common.h"
 #include "../../include/usdm_hip.h"
+#include <type_traits>
 
 namespace {
-constexpr int MW = 16;    // waves per workgroup
-constexpr int MTG = 8;    // tiles per reduction group (LDS: MTG x 16 waves x 1 KiB)
+constexpr int MW = 8;     // waves per workgroup (two per SIMD: 256 registers each, spent on loads in flight)
+constexpr int CH = 16;    // K chunks of 32 a wave can hold activations for (K <= MW * CH * 32 = 4096)
+constexpr int MTG = 16;   // tiles per reduction group (LDS: MTG x MW waves x 1 KiB)
+#ifndef USDM_MFMA_NO_ASM
+#define USDM_MFMA_NO_ASM 0   // 1: the compiler-scheduled stream everywhere (debugging)
+#endif
 constexpr int RED_BYTES = MTG * MW * 64 * 16;
 constexpr int GAM_FLOATS = 4096;
-constexpr int LDS_BYTES = RED_BYTES + GAM_FLOATS * 4 + MW * 16 * 4 + 64 * 4 + 2 * 8 * 16 * 4;
+constexpr int LDS_BYTES = RED_BYTES + GAM_FLOATS * 4 + MW * 16 * 4 + 64 * 4 + 2 * MTG * 16 * 4;
 
 struct MfmaDev {
   usdm_gemv_batch_args ba;
   int ntiles, rt, cpw, nchunks, grid, nout;
+  int dbg_contig;   // form 2 (timing experiment only, WRONG results): every load instruction reads 1 KiB of one row instead of 16 rows x 64 B
 };
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 w, u32x4 x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
 
-template <bool HOLD>
+// CPWT: K chunks per wave as a compile-time constant (16: K = 4096; 56: K = 14336), 0 = read it from the launch (any K).  With a
+// constant every load of the stream loop is unconditional straight-line code; behind per-chunk branches the compiler's wait-count
+// pass gives up at the joins and drains the whole ring (vmcnt(0)) in front of every MFMA - measured: 3.0 instead of ~5 TB/s.
+// Hand-counted loads for the straight-line part of the HOLD stream (cdna_hip_programming.md 5.7, form (ii)): the compiler neither
+// sees these loads nor waits for them; every consumer below waits for exactly its own load (in-order completion: "all but the 23
+// youngest") inside the same asm statement that multiplies it.
+__device__ __forceinline__ void ld_nt_asm(u32x4& dst, const u32x4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int WAIT, bool FIRST>
+__device__ __forceinline__ void wait_mfma_asm(f32x4& acc, const u32x4& w, const u32x4& x) {
+  if constexpr (FIRST)
+    asm volatile("s_waitcnt vmcnt(%3)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x), "n"(WAIT));
+  else
+    asm volatile("s_waitcnt vmcnt(%3)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x), "n"(WAIT));
+}
+
+template <bool HOLD, int CPWT>
 __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   const usdm_gemv_args& a = d.ba.g;
+  const int cpw = CPWT > 0 ? CPWT : d.cpw;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* red = (f32x4*)smem;                               // [MTG][MW][64] partial D fragments
   float* gam = (float*)(smem + RED_BYTES);                 // [K <= 4096] RMSNorm weight
   float* ssum = gam + GAM_FLOATS;                          // [MW][16] partial sums of squares
   int* tl = (int*)(ssum + MW * 16);                        // [MTG] tile ids of the group being reduced
-  float* sv = (float*)(tl + 64);                           // lm_head: [8][16] best value / index per reducing wave and sequence
-  int* si = (int*)(sv + 8 * 16);
+  float* sv = (float*)(tl + 64);                           // lm_head: [MW][16] best value / index per reducing wave and sequence
+  int* si = (int*)(sv + MTG * 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
@@ -66,9 +90,25 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     bool act = false;
     if (lane < ncand) {
       const int t = blockIdx.x + lane * d.grid;
-      for (int r = 0; r < 16 && t * 16 + r < a.N; ++r) act |= (a.ban[t * 16 + r] == 0);
+      if (t * 16 + 16 <= a.N && (((uintptr_t)a.ban) & 15) == 0) {      // one 16-byte load per tile (sixteen dependent byte loads cost ~10 us)
+        const u32x4 bv = *(const u32x4*)(a.ban + t * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) act |= ((bv[e] & 0xff) == 0) | (((bv[e] >> 8) & 0xff) == 0) | (((bv[e] >> 16) & 0xff) == 0) | ((bv[e] >> 24) == 0);
+      } else {
+        for (int r = 0; r < 16 && t * 16 + r < a.N; ++r) act |= (a.ban[t * 16 + r] == 0);
+      }
     }
     mask = __ballot(act);
+    if (a.y32) {      // the logits of tiles that are not streamed: -inf for every sequence (what the sampling kernel expects of banned ids)
+      for (int i = 0; i < ncand; ++i) {
+        if ((mask >> i) & 1ull) continue;
+        const int t = blockIdx.x + i * d.grid;
+        for (int e = tid; e < 16 * nb; e += MW * 64) {
+          const int n = t * 16 + (e & 15);
+          if (n < a.N) a.y32[(int64_t)(e >> 4) * d.ba.y_bs + n] = -INFINITY;
+        }
+      }
+    }
   }
   unsigned long long rem_ld = mask, rem_cp = mask;
   auto next_tile = [&](unsigned long long& m) -> int {
@@ -77,41 +117,88 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     m &= m - 1;
     return (int)blockIdx.x + i * d.grid;
   };
-  // weight row of A-row r16 of tile t (-1: none), and the 16-byte fragment of K chunk c of this wave's slice
-  auto wrow = [&](int t) -> int {
-    if (t < 0) return -1;
+  // Per-lane base of this wave's K slice of tile t (A-row r16), and of the activation slice.  Rows / sequences that do not exist are
+  // CLAMPED to existing ones instead of masked: they only feed output rows / columns that the epilogue never stores, and every load
+  // below stays unconditional (uniform control flow, one 64-bit base + immediates per tile).
+  const int kc0 = wave * cpw;                             // first K chunk of this wave (host: K %% (MW * 32) == 0)
+  auto wbase = [&](int t) -> const u32x4* {
+    int row;
     if (glu) {
-      const int f = t * 8 + (r16 & 7);
-      return f < d.nout ? (f >> 4) * 32 + (f & 15) + (r16 >= 8 ? 16 : 0) : -1;
+      const int f = t < 0 ? 0 : min(t * 8 + (r16 & 7), d.nout - 1);
+      row = (f >> 4) * 32 + (f & 15) + (r16 >= 8 ? 16 : 0);
+    } else {
+      row = t < 0 ? 0 : min(t * d.rt + r16, a.N - 1);
     }
-    const int n = t * d.rt + r16;
-    return (r16 < d.rt && n < a.N) ? n : -1;
+    if (t < 0 && K >= 2048) {
+      // No such tile: the stream loop's loads stay unconditional (uniform wait counts), but they must cost nothing - 64 bytes of the
+      // activation vector per instruction (one request instead of sixteen), a different line for every wave so that no L2 channel
+      // becomes a hot spot (weight row 0 for everyone did).  Row 0 of x holds K * 2 bytes; chunk offsets reach 1 KiB further.
+      const int line = (int)((blockIdx.x * MW + wave) % (unsigned)(K / 32 - 16));
+      return (const u32x4*)a.x + line * 4 + (lane & 3);
+    }
+    if (d.dbg_contig) {
+      // form 2, a TIMING EXPERIMENT with wrong results: the same bytes per tile and wave read row-contiguously - load instruction c
+      // reads 1 KiB of row (first row of the tile + c % 16), all inside the matrix (N >= 16; chunk offsets wrap inside the K slice)
+      const int row0 = min(max(t, 0) * 16, a.N - 16);
+      return (const u32x4*)(Wb + (int64_t)row0 * a.ldw + (int64_t)kc0 * 32 + lane * 8);
+    }
+    return (const u32x4*)(Wb + (int64_t)row * a.ldw + (int64_t)kc0 * 32 + 8 * g);
   };
-  const int kc0 = wave * d.cpw;                             // first K chunk of this wave
-  auto wload = [&](int row, int c) -> u32x4 {
-    if (row < 0 || kc0 + c >= d.nchunks) return u32x4{0u, 0u, 0u, 0u};
-    return __builtin_nontemporal_load((const u32x4*)(Wb + (int64_t)row * a.ldw + (int64_t)(kc0 + c) * 32 + 8 * g));
+  auto wload = [&](const u32x4* base, int c) -> u32x4 {
+    if (d.dbg_contig) {
+      const int kblk = cpw >= 16 ? (c >> 4) % (cpw >> 4) : 0;                 // 512-element blocks inside the wave's K slice
+      return __builtin_nontemporal_load((const u32x4*)((const bf16_t*)base + (int64_t)(c & 15) * a.ldw + kblk * 512));
+    }
+    return __builtin_nontemporal_load(base + c * 4);
   };
-  auto xload = [&](int c) -> u32x4 {
-    if (r16 >= nb || kc0 + c >= d.nchunks) return u32x4{0u, 0u, 0u, 0u};
-    return *(const u32x4*)((const bf16_t*)a.x + (int64_t)r16 * d.ba.x_bs + (int64_t)(kc0 + c) * 32 + 8 * g);
-  };
+  const u32x4* xbase = (const u32x4*)((const bf16_t*)a.x + (int64_t)min(r16, nb - 1) * d.ba.x_bs + (int64_t)kc0 * 32 + 8 * g);
+  auto xload = [&](int c) -> u32x4 { return xbase[c * 4]; };
 
   // ---- loads: the activation slice first (they return first: L2 hits), then the weights of the first two tiles
-  u32x4 xf[8];
-  float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+  u32x4 xf[HOLD ? CH : 1];
+  float4 gv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if constexpr (HOLD) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xf[c] = xload(c);
-    if (a.norm_w && tid * 4 < K) gv = *(const float4*)(a.norm_w + tid * 4);
-  }
-  u32x4 ring[8];                                            // the 8 weight fragments of one tile; slot c is refilled with the NEXT
-  u32x4 rx[HOLD ? 1 : 8];                                   // tile's chunk c as soon as it has been multiplied (8 KiB per wave in flight)
-  const int tA = next_tile(rem_ld), rowA = wrow(tA);
+    for (int c = 0; c < CH; ++c)
+      if (c < cpw) xf[c] = xload(c);
+    if (a.norm_w) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    ring[c] = wload(rowA, c);
-    if constexpr (!HOLD) rx[c] = xload(c);
+      for (int q = 0; q < 2; ++q)
+        if ((tid + q * MW * 64) * 4 < K) gv[q] = *(const float4*)(a.norm_w + (tid + q * MW * 64) * 4);
+    }
+  }
+  // HOLD: a ring of RS = 24 weight fragments = the loads of one and a half tiles (24 KiB per wave, 192 KiB per CU in flight; 32 slots
+  // next to the 16 held activation fragments do not fit 256 registers).  Item j = (tile j / 16, chunk j % 16) lives in slot j % 24 and is
+  // refilled with item j + 24 as soon as it has been multiplied; the stream loop below is unrolled over three tiles so that slot and
+  // chunk indices are constants.  Otherwise (STREAM): CH (weight, activation) pairs.
+  constexpr int RS = 24;
+  u32x4 ring[HOLD ? RS : CH];
+  u32x4 rx[HOLD ? 1 : CH];
+  int t0 = next_tile(rem_ld), t1 = -1, t2 = -1;             // tile being multiplied, the next two (loads in flight / to be issued)
+  const u32x4* wp0 = wbase(t0);
+  const u32x4* wp1 = wp0;
+  const u32x4* wp2 = wp0;
+  constexpr bool ASM_STREAM = HOLD && CPWT == CH && !USDM_MFMA_NO_ASM;     // hand-counted loads (see the stream loop)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (c < cpw) {
+      if constexpr (ASM_STREAM) ld_nt_asm(ring[c], wp0 + c * 4);
+      else ring[c] = wload(wp0, c);
+      if constexpr (!HOLD) rx[c] = xload(c);
+    }
+  }
+  if constexpr (HOLD) {
+    t1 = next_tile(rem_ld);
+    wp1 = wbase(t1);
+#pragma unroll
+    for (int c = 0; c < RS - CH; ++c) {
+      if (c < cpw) {
+        if constexpr (ASM_STREAM) ld_nt_asm(ring[CH + c], wp1 + c * 4);
+        else ring[CH + c] = wload(wp1, c);
+      }
+    }
+    t2 = next_tile(rem_ld);
+    wp2 = wbase(t2);
   }
 
   // ---- RMSNorm of the held activation slice (HF: bf16(bf16(x * rstd) * weight)), under the weight loads
@@ -119,24 +206,29 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     if (a.norm_w) {
       float ss = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+      for (int c = 0; c < CH; ++c)
+        if (c < cpw) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = bf2f(xf[c][e] & 0xffff), hi = bf2f(xf[c][e] >> 16);
-          ss += lo * lo + hi * hi;
+          for (int e = 0; e < 4; ++e) {
+            const float lo = bf2f(xf[c][e] & 0xffff), hi = bf2f(xf[c][e] >> 16);
+            ss += lo * lo + hi * hi;
+          }
         }
+      if (r16 >= nb) ss = 0.f;
       ss += __shfl_xor(ss, 16, 64);
       ss += __shfl_xor(ss, 32, 64);
       if (g == 0) ssum[wave * 16 + r16] = ss;
-      if (tid * 4 < K) *(float4*)(gam + tid * 4) = gv;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if ((tid + q * MW * 64) * 4 < K) *(float4*)(gam + (tid + q * MW * 64) * 4) = gv[q];
       __syncthreads();
       float tot = 0.f;
 #pragma unroll
       for (int w = 0; w < MW; ++w) tot += ssum[w * 16 + r16];
       const float rstd = rsqrtf(tot / (float)K + a.eps);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (kc0 + c < d.nchunks) {
+      for (int c = 0; c < CH; ++c) {
+        if (c < cpw) {
           const float4 g0 = *(const float4*)(gam + (kc0 + c) * 32 + 8 * g), g1 = *(const float4*)(gam + (kc0 + c) * 32 + 8 * g + 4);
           const float gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
@@ -223,11 +315,11 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   auto flush_group = [&](bool more) {
     const int ng = ((done - 1) % MTG) + 1;
     __syncthreads();
-    if (wave < ng) {
-      f32x4 s = red[(wave * MW) * 64 + lane];
+    for (int slot = wave; slot < ng; slot += MW) {
+      f32x4 s = red[(slot * MW) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < MW; ++w) s += red[(wave * MW + w) * 64 + lane];
-      epilogue(tl[wave], s);
+      for (int w = 1; w < MW; ++w) s += red[(slot * MW + w) * 64 + lane];
+      epilogue(tl[slot], s);
     }
     if (more) __syncthreads();
   };
@@ -241,39 +333,91 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
 
   // ---- stream
   if constexpr (HOLD) {
-    while (true) {
-      const int t = next_tile(rem_cp);
-      if (t < 0) break;
-      const int tn = next_tile(rem_ld), rown = wrow(tn);
+    // one tile at ring phase P (its chunk c sits in slot (16 P + c) % 24); returns false after the last tile
+    auto tile_phase = [&](auto P, auto STATIC) __attribute__((always_inline)) -> bool {
+      constexpr int ph = decltype(P)::value;
+      constexpr bool stat = decltype(STATIC)::value;
+      if (t0 < 0) return false;
+      (void)next_tile(rem_cp);                               // (rem_cp = the tiles after this one: finish_tile's "more")
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { acc = mfma16(ring[c], xf[c], acc); if (tn >= 0) ring[c] = wload(rown, c); }
-      finish_tile(t, acc);
+      for (int c = 0; c < CH; ++c) {
+        const int sl = (CH * ph + c) % RS;
+        if (c < cpw) {
+          // item + 24 = (next tile, chunk c + 8) for c < 8, (tile after next, chunk c - 8) otherwise
+          const u32x4* np = c < RS - CH ? wp1 + (c + (RS - CH)) * 4 : wp2 + (c - (RS - CH)) * 4;
+          if constexpr (stat) {
+            if (c == 0) wait_mfma_asm<RS - 1, true>(acc, ring[sl], xf[c]);
+            else wait_mfma_asm<RS - 1, false>(acc, ring[sl], xf[c]);
+            ld_nt_asm(ring[sl], np);
+          } else {
+            acc = mfma16(ring[sl], xf[c], acc);
+            if ((c < RS - CH ? c + (RS - CH) : c - (RS - CH)) < cpw) ring[sl] = __builtin_nontemporal_load(np);
+            __builtin_amdgcn_sched_barrier(0);               // keep (multiply, refill) pairs in program order
+          }
+        }
+      }
+      if constexpr (stat) {                                  // straight-line part: at most MTG tiles, no flush in between
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));     // the last MFMA's result before the compiler's own code reads it
+        red[(done * MW + wave) * 64 + lane] = acc;
+        if (tid == 0) tl[done] = t0;
+        ++done;
+      } else {
+        finish_tile(t0, acc);
+      }
+      t0 = t1; t1 = t2; wp1 = wp2;
+      t2 = next_tile(rem_ld);
+      wp2 = wbase(t2);
+      return true;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    if constexpr (ASM_STREAM) {
+      // The first 12 tiles (every production launch has at most 11 per workgroup) as STRAIGHT-LINE code with hand-counted loads.
+      // Left to the compiler, the wait-count pass puts vmcnt(7) in front of the first eight MFMAs of every tile - in the looped AND in
+      // the straight-line form, with the (multiply, refill) pairs pinned in program order - although 23 younger loads are in flight:
+      // the ring drains to a third every tile (measured: 3.0 TB/s against 5.9 for the batch-1 kernel).  The ring's first fill above is
+      // hand-counted as well (a compiler-issued fill would be waited for with counts that ignore the asm loads: a full drain).
+      static_assert(MTG >= 12, "the straight-line part must fit one reduction group");
+      using T = std::true_type;
+      do {
+        if (!tile_phase(I0{}, T{})) break; if (!tile_phase(I1{}, T{})) break; if (!tile_phase(I2{}, T{})) break;
+        if (!tile_phase(I0{}, T{})) break; if (!tile_phase(I1{}, T{})) break; if (!tile_phase(I2{}, T{})) break;
+        if (!tile_phase(I0{}, T{})) break; if (!tile_phase(I1{}, T{})) break; if (!tile_phase(I2{}, T{})) break;
+        if (!tile_phase(I0{}, T{})) break; if (!tile_phase(I1{}, T{})) break; if (!tile_phase(I2{}, T{})) break;
+      } while (false);
+      // drain: loads for tiles that do not exist (row 0) may still be in flight into ring registers; naming all 24 as inputs keeps
+      // the compiler from reusing any of them before the wait has executed
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(ring[0]), "v"(ring[1]), "v"(ring[2]), "v"(ring[3]), "v"(ring[4]), "v"(ring[5]), "v"(ring[6]), "v"(ring[7]),
+                   "v"(ring[8]), "v"(ring[9]), "v"(ring[10]), "v"(ring[11]), "v"(ring[12]), "v"(ring[13]), "v"(ring[14]), "v"(ring[15]),
+                   "v"(ring[16]), "v"(ring[17]), "v"(ring[18]), "v"(ring[19]), "v"(ring[20]), "v"(ring[21]), "v"(ring[22]), "v"(ring[23])
+                   : "memory");
     }
+    using F = std::false_type;
+    while (tile_phase(I0{}, F{}) && tile_phase(I1{}, F{}) && tile_phase(I2{}, F{})) {}
   } else {
-    // activations streamed beside the weights (K slices longer than 8 chunks: down_proj): a ring of 8 (weight, activation) pairs,
-    // each refilled 8 chunks ahead as soon as it has been multiplied
+    // activations streamed beside the weights (K slices longer than CH chunks: down_proj): a ring of CH (weight, activation) pairs,
+    // each refilled CH chunks ahead as soon as it has been multiplied
     int t = next_tile(rem_cp);
-    int row = rowA;
+    const u32x4* wp = wp0;
     while (t >= 0) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int c0 = 0; c0 < d.cpw; c0 += 8) {
+      for (int c0 = 0; c0 < cpw; c0 += CH) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (c0 + u < d.cpw) {
+        for (int u = 0; u < CH; ++u) {
+          if (c0 + u < cpw) {
             acc = mfma16(ring[u], rx[u], acc);
-            const int cn = c0 + u + 8;
-            if (cn < d.cpw) { ring[u] = wload(row, cn); rx[u] = xload(cn); }
+            const int cn = c0 + u + CH;
+            if (cn < cpw) { ring[u] = wload(wp, cn); rx[u] = xload(cn); }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
       finish_tile(t, acc);
       t = next_tile(rem_cp);
-      row = wrow(t);
-      if (t >= 0) {
+      wp = wbase(t);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { ring[c] = wload(row, c); rx[c] = xload(c); }
-      }
+      for (int c = 0; c < CH; ++c)
+        if (c < cpw) { ring[c] = wload(wp, c); rx[c] = xload(c); }
     }
   }
   if (done % MTG) flush_group(false);
@@ -281,12 +425,12 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   // ---- lm_head: per-workgroup arg-max partial of every sequence (ties -> lowest id); unused partial slots keep "no candidate"
   if (lmh) {
     __syncthreads();
-    if (wave < 8 && g == 0) { sv[wave * 16 + r16] = bestv; si[wave * 16 + r16] = besti; }
+    if (g == 0) { sv[wave * 16 + r16] = bestv; si[wave * 16 + r16] = besti; }
     __syncthreads();
     if (tid < nb) {
       float bv = sv[tid];
       int bi = si[tid];
-      for (int w = 1; w < 8; ++w) {
+      for (int w = 1; w < MW; ++w) {
         const float v = sv[w * 16 + tid];
         const int i = si[w * 16 + tid];
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
@@ -306,13 +450,15 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
 int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   const usdm_gemv_args& a = pa->g;
   USDM_CHECK_ARG(pa->nb >= 1 && pa->nb <= 16, "usdm_gemv_batch (matrix-core form): 1..16 sequences per step");
-  USDM_CHECK_ARG(a.K % 32 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K && pa->x_bs % 8 == 0, "usdm_gemv_batch (matrix-core form): K %% 32, ldw %% 8, x stride %% 8");
+  USDM_CHECK_ARG(a.K % (MW * 32) == 0 && a.ldw % 8 == 0 && a.ldw >= a.K && pa->x_bs % 8 == 0,
+                 "usdm_gemv_batch (matrix-core form): K %% %d, ldw %% 8, x stride %% 8", MW * 32);
   const bool glu = a.act == USDM_ACT_SWIGLU, lmh = a.part_val != nullptr;
   MfmaDev d;
   d.ba = *pa;
   d.nchunks = a.K / 32;
+  d.dbg_contig = (pa->form == 2 && a.N >= 16 && d.nchunks / MW >= 16) ? 1 : 0;      // (needs K slices of >= 512 elements)
   d.cpw = cdiv(d.nchunks, MW);
-  const bool hold = d.cpw <= 8;
+  const bool hold = d.cpw <= CH;
   USDM_CHECK_ARG(!a.norm_w || (hold && a.K <= GAM_FLOATS && a.K % 4 == 0), "usdm_gemv_batch (matrix-core form): the fused RMSNorm needs K <= 4096");
   USDM_CHECK_ARG(!lmh || (a.part_idx && !glu), "usdm_gemv_batch: lm_head partial buffers");
   d.nout = glu ? a.N / 2 : a.N;
@@ -334,16 +480,17 @@ int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   d.grid = d.ntiles < 256 ? d.ntiles : 256;
   USDM_CHECK_ARG(cdiv(d.ntiles, d.grid) <= 64, "usdm_gemv_batch (matrix-core form): N too large (more than 64 tiles per workgroup)");
   USDM_CHECK_ARG(!lmh || pa->part_bs >= d.grid, "usdm_gemv_batch: part_bs must hold one partial per workgroup (%d)", d.grid);
-  auto kh = gemv_mfma_kernel<true>;
-  auto ks = gemv_mfma_kernel<false>;
+  void (*kfn)(const MfmaDev) = hold ? (d.cpw == 16 ? gemv_mfma_kernel<true, 16> : gemv_mfma_kernel<true, 0>)
+                                    : (d.cpw == 56 ? gemv_mfma_kernel<false, 56> : gemv_mfma_kernel<false, 0>);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
-  if (hold) hipLaunchKernelGGL(kh, dim3(d.grid), dim3(MW * 64), LDS_BYTES, st, d);
-  else hipLaunchKernelGGL(ks, dim3(d.grid), dim3(MW * 64), LDS_BYTES, st, d);
+  hipLaunchKernelGGL(kfn, dim3(d.grid), dim3(MW * 64), LDS_BYTES, st, d);
   USDM_LAUNCH_CHECK();
   return 0;
 }

@@ -615,6 +615,11 @@ class USDMForCausalLM:
         Z = lambda *s, dt=bf: plan.hold(torch.zeros(*s, device=dev, dtype=dt))
         h, qkv, ao, act = bb["h"], Z(B, nq), Z(B, Hq * d), Z(B, I)
         NS = max(2, self.NS)
+        if B > 4:
+            # many sequences: B x Hkv x NS workgroups of ctx / NS keys each.  The batch-1 choice (32 splits of ~20 keys: latency-bound,
+            # one per CU) would be 4096 tiny workgroups at B = 16 (measured 35.6 us per layer); ~512 workgroups with up to 512 keys
+            # (the split kernel's LDS bound) keep the KV stream at full width.  (B <= 4 keeps the batch-1 splits: bit-identical.)
+            NS = max(-(-self.ctx_max // 512), min(self.NS, max(2, 512 // (B * Hkv))))
         pm, pl, po = Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS * d, dt=torch.float32)
         cache_bs = L * Hkv * self.ctx_max * d
         for l in range(L):
