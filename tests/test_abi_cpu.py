@@ -19,11 +19,14 @@ def test_library_exports_every_declared_symbol():
     # opt-in kernels that measured slower than the default live in their own header, outside the stable C-ABI
     exp = set(re.findall(pat, open(os.path.join(ROOT, "include", "usdm_hip_experimental.h")).read(), flags=re.M))
     assert exp == {"usdm_gemv_chain", "usdm_gemv_engine"} and not (exp & names), exp
-    names |= exp
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
     assert _lib.lib.usdm_abi_version() >= 1
+    # ... and in their own BINARY (round 4): the product library does not carry them, libusdm_hip_experimental.so does
+    assert not [n for n in sorted(exp) if hasattr(lib, n)], "experimental kernels leaked into the product library"
+    elib = _lib.exp()
+    assert not [n for n in sorted(exp) if not hasattr(elib, n)]
 
 
 def test_bad_arguments_are_reported_not_crashed():

@@ -18,10 +18,10 @@ for W in Ws:
     ops.gemv_engine([ops.gemv(W, h, N=2 * I, K=H, norm_w=ln, eps=1e-5, act=3, y16=act, only_args=True)], sync, gran, timeout_ms=300, plan=plan)
 plan.run(); torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
-_lib.lib.usdm_dbg_eng_trace(buf, 1)
+_lib.exp().usdm_dbg_eng_trace(buf, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); plan.run(); e1.record(); torch.cuda.synchronize()
-_lib.lib.usdm_dbg_eng_trace(buf, 0)
+_lib.exp().usdm_dbg_eng_trace(buf, 0)
 us = e0.elapsed_time(e1) * 1e3 / NLAY
 print(f"gate/up engine launch: {us:.1f} us; per launch, cycles of workgroup 0 (clock64):")
 names = {0: "wait free slot", 1: "issue DMAs", 2: "wait DMAs landed"}

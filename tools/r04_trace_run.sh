@@ -3,7 +3,5 @@ cd $GRAFT_REPO_ROOT
 USDM_EXTRA_HIPCC_FLAGS=-DUSDM_GEMM_TRACE python -m usdm_amd.build --force > gpurun_out/r04_trace_build.log 2>&1
 for t in 12 15; do
   echo "=== tile $t, 2236 x 3072 x 1024 plain bf16"; USDM_GEMM_TILE=$t python tools/gemm_trace.py 2236 3072 1024
-  for abl in 7 3; do if [ $t = 15 ]; then echo "--- tile 15 abl $abl"; USDM_GEMM_TILE=$t USDM_GEMM_ABL=$abl python tools/gemm_trace.py 2236 3072 1024 | head -12; fi; done
 done
 echo "=== tile 16 w1 gelu"; USDM_GEMM_TILE=16 python tools/gemm_trace.py 2236 4096 1024 --gelu
-echo "=== tile 13 w1 gelu"; USDM_GEMM_TILE=13 python tools/gemm_trace.py 2236 4096 1024 --gelu

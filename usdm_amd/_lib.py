@@ -18,8 +18,25 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `python -m usdm_amd.build` (hipcc --offload-arch=gfx950). "
         "usdm_amd has no CPU fallback.")
 
-lib = C.CDLL(LIB_PATH)
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # (global: the experimental library resolves usdm_set_error here)
 lib.usdm_last_error.restype = C.c_char_p
+_exp = None
+
+
+def exp():
+    """libusdm_hip_experimental.so (include/usdm_hip_experimental.h): kernels that measured slower than the default path, kept out of
+    the product library; loaded on first use by ops.gemv_chain / ops.gemv_engine only."""
+    global _exp
+    if _exp is None:
+        path = os.path.join(_HERE, "libusdm_hip_experimental.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: build it with `python -m usdm_amd.build`")
+        e = C.CDLL(path)
+        n = e.usdm_sizeof_gemv_chain_args()
+        if n != C.sizeof(GemvChainArgs):
+            raise ImportError(f"ABI mismatch: usdm_gemv_chain_args is {n} bytes in the library, {C.sizeof(GemvChainArgs)} in Python")
+        _exp = e
+    return _exp
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 3, 4, 5
@@ -189,7 +206,7 @@ def _selfcheck():
     for name, cls in (("norm", NormArgs), ("snake", SnakeArgs), ("attn", AttnArgs), ("vb_input", VbInputArgs),
                       ("vb_solver", VbSolverArgs), ("gemv", GemvArgs), ("decode_state", DecodeState),
                       ("rope", RopeArgs), ("attn_decode", AttnDecodeArgs), ("sample", SampleArgs),
-                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev), ("gemv_chain", GemvChainArgs)):
+                      ("gemv_batch", GemvBatchArgs), ("p2p_dev", P2pDev)):
         n = getattr(lib, f"usdm_sizeof_{name}" if name in ("decode_state", "p2p_dev") else f"usdm_sizeof_{name}_args")()
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: usdm_{name}_args is {n} bytes in the library, {C.sizeof(cls)} in Python")

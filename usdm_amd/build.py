@@ -20,6 +20,13 @@ FLAGS += os.environ.get("USDM_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DUSDM_GEM
 EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+# Kernels that measured SLOWER than the default path (profiles/r02_decode_ablation.txt 3-4, profiles/r03_tp_ablation.txt) are kept for
+# the record and their tests, but not in the product library: they build into libusdm_hip_experimental.so, which nothing loads
+# unless usdm_amd.ops.gemv_chain / gemv_engine are called (include/usdm_hip_experimental.h).
+EXPERIMENTAL = {"llm_chain_k.hip", "llm_engine_k.hip"}
+OUT_EXP = os.path.join(HERE, "libusdm_hip_experimental.so")
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -37,10 +44,11 @@ def build(force=False, verbose=True):
     objs, jobs = [], []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
+    objs_exp = []
     for s in _sources():
         src = os.path.join(CSRC, s)
         obj = os.path.join(bdir, s.replace(".hip", ".o"))
-        objs.append(obj)
+        (objs_exp if s in EXPERIMENTAL else objs).append(obj)
         if force or _stale(obj, src):
             jobs.append([HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
@@ -55,8 +63,10 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(OUT):
+    if jobs or not os.path.exists(OUT) or not os.path.exists(OUT_EXP):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+        # the experimental kernels resolve usdm_set_error (csrc/core.hip) in the product library, next to which they are installed
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT_EXP, *objs_exp, "-L" + HERE, "-lusdm_hip", "-Wl,-rpath,$ORIGIN"])
     return OUT
 
 

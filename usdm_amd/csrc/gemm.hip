@@ -23,6 +23,7 @@
 #include "../../include/usdm_hip.h"
 #include <stdlib.h>
 #include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -57,8 +58,16 @@ __device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
 // debugging aid (tools/gemm_trace.py): per-workgroup phase timestamps (100 MHz wall clock) + hardware ids
 __device__ unsigned long long g_gemm_trace[8192 * 8];
 #define TR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// shader-clock stamps inside ONE K-step of the K-split loop (wave 0 of every workgroup, step KTR_STEP): barrier released, MFMAs +
+// reads + DMA issued, LDS reads retired, DMA of step s + 2 retired, next barrier released; + the 100 MHz clock at both ends
+__device__ unsigned long long g_gemm_trace2[8192 * 8];
+#define KTR_STEP 8
+#define KTR(i, s) do { if ((s) == KTR_STEP && threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace2[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KTRW(i, s) do { if ((s) == KTR_STEP && threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace2[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define TR(i) do { } while (0)
+#define KTR(i, s) do { } while (0)
+#define KTRW(i, s) do { } while (0)
 #endif
 
 // bias of this thread's epilogue columns -> registers (SwiGLU: gate / up), per-column bias of the transposed epilogues -> LDS.
@@ -316,32 +325,37 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     }
   }
   // part 0 / 1: the instructions issued in the first / second phase of a step; 2: all.  chk: the step's second half lies past K
-  auto pp_issue = [&](int slot, int step, int part, bool chk) {
+  // chk: 1 = the step's second half lies past K (those lanes read zeros), 2 = the whole step does (a placeholder issue: range-checked
+  // away, no memory traffic); only >= 0: just that instruction of the step (PNF = the leftover half instruction)
+  // source columns of a step: W is [N][taps * Kc]; A adds a_tap_stride per tap (operands concatenated along K from several sources:
+  // a_row_step == 0, Kc % 64 == 0, so a step never straddles two taps and the remap is one scalar division)
+  auto pp_cols = [&](int step, unsigned& kcolA, unsigned& kcolW) {
+    const int q = q_lo + 2 * step;
+    kcolW = (unsigned)(q * 64);
+    kcolA = kcolW;
+    if (a.taps > 1) {
+      const int tap = q / cpt;
+      kcolA = (unsigned)(((int64_t)(q - tap * cpt) * CE + (int64_t)tap * a.a_tap_stride) * ES);
+    }
+  };
+  auto pp_issue = [&](int slot, int step, int part, int chk, int only = -1, unsigned kcolA = 0u, unsigned kcolW = 0u) {
     if constexpr (PP) {
       char* sAs = smem + slot * STAGE;
       char* sBs = sAs + BM * 128;
-      // source columns of the step: W is [N][taps * Kc]; A adds a_tap_stride per tap (operands concatenated along K from
-      // several sources: a_row_step == 0, Kc % 64 == 0, so a step never straddles two taps and the remap is one scalar division)
-      const int q = q_lo + 2 * step;
-      const unsigned kcolW = (unsigned)(q * 64);
-      unsigned kcolA = kcolW;
-      if (a.taps > 1) {
-        const int tap = q / cpt;
-        kcolA = (unsigned)(((int64_t)(q - tap * cpt) * CE + (int64_t)tap * a.a_tap_stride) * ES);
-      }
+      if (only < 0) pp_cols(step, kcolA, kcolW);      // (single-instruction calls bring the step's columns with them)
 #pragma unroll
       for (int i = 0; i < PNF; ++i) {
-        if (part != 2 && (i < PNF / 2) != (part == 0)) continue;
+        if (only >= 0 ? i != only : (part != 2 && (i < PNF / 2) != (part == 0))) continue;
         unsigned off = pofs[i] + (i < PFA ? kcolA : kcolW);
-        if (chk && ((phi >> i) & 1)) off = OOB;
+        if (chk == 2 || (chk && ((phi >> i) & 1))) off = OOB;
         if (i < PFA)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (wv + NWV * i) * 1024), 16, off, 0, 0, 0);
         else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sBs + (wv + NWV * (i - PFA)) * 1024), 16, off, 0, 0, 0);
       }
-      if (PLA && part != 0) {
+      if (PLA && (only >= 0 ? only == PNF : part != 0)) {
         unsigned off = pofs[PNF] + kcolA;
-        if (chk && ((phi >> PNF) & 1)) off = OOB;
+        if (chk == 2 || (chk && ((phi >> PNF) & 1))) off = OOB;
         if ((lane >> 5) == (wv & 1))
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sAs + (PFA * NWV + (wv >> 1)) * 1024), 16, off, 0, 0, 0);
       }
@@ -402,35 +416,38 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     const int nst = nks;                                   // K-steps (NCH = 2 chunks each)
     const bool odd_tail = ((q_hi - q_lo) & 1) != 0;        // the last step has only its first half
    if constexpr (KSP) {
-    // ---- K-split ping-pong (round 4).  What bounded the loop below (profiles/r03_vb_ablation.txt 9): a 64 x 64 wave tile reads
-    // 8 KB of fragments per 16 MFMAs, so the partner wave's load segment (4 waves x 8 KB through a 128 B/clk LDS port + read latency
-    // + its share of the LDS-DMA issue, ~500 cycles) is twice as long as the 256 cycles of MFMA it is supposed to hide under.
-    // Here the 8 waves are two groups of NWM x NWN waves that BOTH cover the whole BM x BN tile (wave tile 128 x 64 / 144 x 64:
-    // 12 / 13 fragment reads per 32 / 36 MFMAs - the ratio of the 128 x 64 wave tile, without the 256 x 256 workgroup tile it would
-    // otherwise need); group g multiplies K half g of every 64-deep step.  Waves w and w + 4 share a SIMD and still run one
-    // barrier apart, so one of them multiplies (512 - 576 cycles of MFMA) while the other reads and issues the DMA (48 - 52 KB
-    // through the LDS port = 384 - 416 cycles + latency): balanced, and two barriers per K-step instead of four.
-    //   RAW  the counted vmcnt that retires step s + 1 sits before the FIRST barrier of phase s in both groups (group 0: B(2s),
-    //        group 1: B(2s + 1)); group 0 reads step s + 1 after B(2s + 1), group 1 after B(2s + 2);
-    //   WAR  slot (s + 2) % 3 held step s - 1, whose last reads (group 1) were retired by lgkmcnt(0) before B(2s - 1); group 0
-    //        issues step s + 2 after B(2s - 1), group 1 after B(2s).
+    // ---- K-split tiles, ONE barrier per K-step (round 4).  Measured on the ping-pong loop below (profiles/r04_gemm_ablation.txt):
+    // its skeleton (two barriers per phase, nothing else) costs 3.8 us of a 13.3 us K loop, its fragment reads 3.2 us (the LDS array
+    // delivers ~200 B/clk: the port is NOT the limit, contrary to the round-3 reading), its MFMAs 6.4 us - and the three ADD, in the
+    // 64 x 64-wave-tile form and in a two-group K-split form alike: a wave's read -> barrier -> multiply -> barrier chain is serial
+    // and the partner's work overlaps far less than the schedule suggests.  So the chain is cut instead of re-balanced:
+    //   * the 8 waves are two groups of NWM x NWN waves that BOTH cover the whole BM x BN tile (wave tile 128 x 64 / 144 x 64:
+    //     12 / 13 fragment reads per 32 / 36 MFMAs); group g multiplies K half g of every 64-deep step;
+    //   * the fragments of step s + 1 are read WHILE step s is multiplied, by the same wave: A fragment i is reloaded right after
+    //     its four MFMAs (single-buffered: 28 MFMAs lie between the reload and the next use), the four W fragments alternate
+    //     between two register sets (the step loop is unrolled by two); nothing waits for LDS inside a step;
+    //   * the LDS-DMA of step s + 3 is issued between the MFMAs of step s (one instruction per row block: the other wave of the
+    //     SIMD keeps the matrix pipe busy meanwhile) into the slot whose fragments this step already holds in registers: three
+    //     slots give a prefetch distance of TWO steps (the ping-pong loop: one);
+    //   * one s_barrier per step, all eight waves in phase.  Before it every wave has retired its fragment reads (lgkmcnt(0):
+    //     WAR for the slot refilled next) and the DMA of step s + 2 (counted vmcnt: RAW for the reads of the next step).
     // A K that ends in half a step leaves group 1's half of the last step zero-filled (the DMA's range check): it adds zeros.
     // The two groups' accumulators are summed after the loop (each wave keeps the columns [grp * WTN / 2, +WTN / 2) of its wave
     // tile): every output is (sum over even K halves) + (sum over odd K halves) - a fixed order, but not the order of the other
     // tiles (tests/test_gemm_gpu.py::test_ksplit_pingpong_tiles compares against them at f32 rounding level, not bit for bit).
     TR(1);
-    if (nst > 0) pp_issue(0, 0, 2, nst == 1 && odd_tail);
-    if (nst > 1) pp_issue(1, 1, 2, nst == 2 && odd_tail);
-    if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // steps past the end are issued as placeholders (2) and their fragments read as garbage that nothing uses: every step of the
+    // loop is then the SAME straight-line code (no run-time tests inside: at a join the compiler's wait-count pass waits for the LDS
+    // in front of every MFMA group, the serialisation this loop exists to remove)
+    auto chk_of = [&](int step) -> int { return step >= nst ? 2 : ((odd_tail && step == nst - 1) ? 1 : 0); };
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pp_issue(p, p, 2, chk_of(p));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
     __builtin_amdgcn_s_barrier();
     TR(2);
-    // (the bias is fetched AFTER the loop in this variant: eight registers less across it)
-    if (grp == 1) __builtin_amdgcn_s_barrier();
     // Fragment addresses: ONE per-lane base per operand (this group's K half of row block 0 of the wave tile); row block i lies
     // 16 rows = 2048 bytes further on (the swizzle only looks at row bits 1..2 and the K half), so every ds_read_b128 below is
-    // base + an immediate.  (Twelve precomputed addresses per LDS slot - what the compiler makes of a table of offsets - cost 36
-    // registers next to the 128 accumulators and spilled into the loop.)
+    // base + an immediate.
     unsigned fbaseA, fbaseK, fbaseS;           // A; W blocks this group keeps; W blocks it sends after the loop
     {
       const int r = wm * WTM + lr;
@@ -441,54 +458,67 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
       fbaseK = (BM * 128 + (rk >> 3) * 1024 + (rk & 7) * 128 + ((lc ^ ((rk >> 1) & 7)) << 4)) ^ (grp << 6);
       fbaseS = (BM * 128 + (rs >> 3) * 1024 + (rs & 7) * 128 + ((lc ^ ((rs >> 1) & 7)) << 4)) ^ (grp << 6);
     }
-    u32x4 fa[TM], fb[TN];
-    auto kphase = [&](const int slot, const int slotn, const int sn, const bool issue, const bool chk, const int wait_n) {
-      const char* sA = smem + slot * STAGE + fbaseA;
-      const char* sK = smem + slot * STAGE + fbaseK;
-      const char* sSn = smem + slot * STAGE + fbaseS;
-      if (!(g.abl & 4)) {
+    u32x4 fa[TM], fb0[TN], fb1[TN];
+    static_assert(TM >= TN && TM > NPW, "rolling schedule: one W fragment / one DMA instruction behind each of the first row blocks");
+    auto rd_b = [&](u32x4* fb, int slot, int j) {
+      fb[j] = *(const u32x4*)(smem + slot * STAGE + (j < TN / 2 ? fbaseK + j * 2048 : fbaseS + (j - TN / 2) * 2048));
+    };
+    auto rd_a = [&](int slot, int i) { fa[i] = *(const u32x4*)(smem + slot * STAGE + fbaseA + i * 2048); };
+    // step 0's fragments, plainly
 #pragma unroll
-        for (int j = 0; j < TN / 2; ++j) { fb[j] = *(const u32x4*)(sK + j * 2048); fb[j + TN / 2] = *(const u32x4*)(sSn + j * 2048); }
+    for (int j = 0; j < TN; ++j) rd_b(fb0, 0, j);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(sA + i * 2048);
-      }
-      if (issue && !(g.abl & 1)) pp_issue(slotn, sn, 2, chk);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wait_n > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-      else if (wait_n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < TM; ++i) rd_a(0, i);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                            // lgkmcnt(0)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                     // step 1 landed (step 2 may be in flight)
+    // One K-step: multiply step s out of (fa, fbc), read step s + 1 into (fa, fbn), issue the DMA of step s + 3 into slot s % 3
+    auto kstep = [&](const int s, const int sl, const int sl1, u32x4* fbc, u32x4* fbn) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (!(g.abl & 2))
+      KTR(4, s - 1); KTRW(6, s - 1);
+      KTR(0, s); KTRW(5, s);
+      const int chk = chk_of(s + 3);
+      unsigned kcA, kcW;
+      pp_cols(s + 3, kcA, kcW);
       static_for<TM>([&](auto I) {
         static_for<TN>([&](auto J) {
-          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fb[J]),
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fbc[J]),
                                                               acc[I][J], 0, 0, 0);
         });
+        rd_a(sl1, I);
+        if constexpr (I < TN) rd_b(fbn, sl1, I);
+        // LDS-DMA issue, STAGGERED between the two waves of a SIMD: an issue stalls its wave for ~56 cycles (stamps: with both
+        // waves issuing behind the same row blocks the MFMA section took 1360 cycles instead of 1024); group 0 issues behind its
+        // first row blocks, group 1 behind its last ones, so the other wave's MFMAs fill the pipe meanwhile
+        constexpr int NI = PNF + (PLA ? 1 : 0), NB2 = (NI + 1) / 2;   // instructions per wave and step; row blocks that carry two
+        static_assert(2 * NB2 <= TM, "the two groups' issue windows must not overlap");
+        if constexpr (I < NB2) {
+          if (grp == 0) { pp_issue(sl, s + 3, 2, chk, 2 * I, kcA, kcW); if constexpr (2 * I + 1 < NI) pp_issue(sl, s + 3, 2, chk, 2 * I + 1, kcA, kcW); }
+        }
+        if constexpr (I >= TM - NB2) {
+          constexpr int q = I - (TM - NB2);
+          if (grp == 1) { pp_issue(sl, s + 3, 2, chk, 2 * q, kcA, kcW); if constexpr (2 * q + 1 < NI) pp_issue(sl, s + 3, 2, chk, 2 * q + 1, kcA, kcW); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       });
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      KTR(1, s);
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                          // lgkmcnt(0): this step's fragment reads retired
+      KTR(2, s);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                   // step s + 2 landed (s + 3 in flight)
+      KTR(3, s);
     };
-    // ONE copy of the phase with a runtime (scalar) slot: unrolling over the three slots made the compiler rotate the 128
-    // accumulators through different registers in each copy (MFMA D != C) and run out of registers
-    int s = 0, sl = 0, sln = 2;
+    {
+      int s = 0, sl = 0, sl1 = 1;
+      auto adv = [&]() { ++s; if (++sl == 3) sl = 0; if (++sl1 == 3) sl1 = 0; };
 #pragma unroll 1
-    for (; s + 2 < nst - (odd_tail ? 1 : 0); ++s) {        // steady state: every step issues a whole step
-      kphase(sl, sln, s + 2, true, false, 1);
-      if (++sl == 3) sl = 0;
-      if (++sln == 3) sln = 0;
+      for (; s + 1 < nst;) {
+        kstep(s, sl, sl1, fb0, fb1); adv();
+        kstep(s, sl, sl1, fb1, fb0); adv();
+      }
+      if (s < nst) kstep(s, sl, sl1, fb0, fb1);
     }
-#pragma unroll 1
-    for (; s < nst; ++s) {                                  // the last steps: no issue past the end, the final DMA drained
-      const bool more = s + 2 < nst;
-      const bool chk = odd_tail && s + 2 == nst - 1;
-      kphase(sl, sln, s + 2, more, chk, more ? 1 : 0);
-      if (++sl == 3) sl = 0;
-      if (++sln == 3) sln = 0;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the placeholder issues of the last steps (they write zeros into the slots)
     __syncthreads();
     // ---- exchange: every wave hands the half of its accumulators it does not keep (columns of the OTHER group) to the wave with
     // the same wave tile in the other group (wave ^ 4) and adds what it receives.  [wave][fragment][lane] x 16 B: conflict-free.
@@ -1071,6 +1101,9 @@ int launch(const usdm_gemm_args& a, hipStream_t st) {
 #ifdef USDM_GEMM_TRACE
 extern "C" int usdm_dbg_gemm_trace(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * n);
+}
+extern "C" int usdm_dbg_gemm_trace2(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace2), sizeof(unsigned long long) * n);
 }
 #endif
 

@@ -273,7 +273,7 @@ def gemv_engine(phases, sync, gran, timeout_ms=2000, plan=None):
     for i, ph in enumerate(phases):
         c.ph[i] = ph
     c.nph, c.sync, c.timeout_ms, c.gran = len(phases), _ptr(sync), timeout_ms, _ptr(gran)
-    _go(plan, "usdm_gemv_engine", lib.usdm_gemv_engine, C_.byref(c))
+    _go(plan, "usdm_gemv_engine", _lib.exp().usdm_gemv_engine, C_.byref(c))
 
 
 def gemv_chain(phases, sync, timeout_ms=2000, plan=None):
@@ -286,7 +286,7 @@ def gemv_chain(phases, sync, timeout_ms=2000, plan=None):
     for i, ph in enumerate(phases):
         c.ph[i] = ph
     c.nph, c.sync, c.timeout_ms = len(phases), _ptr(sync), timeout_ms
-    _go(plan, "usdm_gemv_chain", lib.usdm_gemv_chain, C_.byref(c))
+    _go(plan, "usdm_gemv_chain", _lib.exp().usdm_gemv_chain, C_.byref(c))
 
 
 def p2p_reduce(p2p, site, n, h, skip=None, plan=None):
