@@ -321,104 +321,6 @@ def test_pingpong_tiles_bit_identical(dev, tile, tile_env):
             assert torch.equal(x, y), f"qkv S={S}: tile {tile} differs from tile 4"
 
 
-@pytest.mark.parametrize("tile", [15, 16])
-def test_ksplit_pingpong_tiles(dev, tile, tile_env):
-    """K-split ping-pong tiles (256x128 / 288x128 with two wave groups, USDM_GEMM_TILE=15 / 16; round 4): group g accumulates K half g
-    of every 64-deep step and the halves are summed once after the loop, so an output is (even halves) + (odd halves) - a fixed
-    order but not the other tiles' order.  Against tile 4 (same operands, same epilogues): equal to f32 rounding of the
-    accumulation (1e-5 of the output scale; bf16 outputs within one ulp), on the shapes of the bit-identity test above - ragged
-    M / N, a K that ends in half a step (group 1's half of the last step is zero-filled), split-K, batched operand with a row
-    offset, two sources along K, head-split and transposed epilogues (tile 16 routes those to tile 15) - and against float64."""
-    from usdm_amd import ops
-
-    def run(t, f):
-        tile_env(t)
-        return f()
-
-    def close(x, y, what):
-        if x.dtype == torch.bfloat16:       # one bf16 ulp of the larger magnitude, plus the f32 accumulation difference near zero
-            xf, yf = x.float(), y.float()
-            tol = 2.0 ** -7 * torch.maximum(xf.abs(), yf.abs()) + 1e-5 * xf.abs().max()
-            assert bool(((xf - yf).abs() <= tol).all()), f"{what}: bf16 outputs differ by more than an ulp"
-        else:
-            m = torch.isfinite(x)
-            assert torch.equal(m, torch.isfinite(y)), f"{what}: written elements differ"
-            d = (x[m].double() - y[m].double()).abs().max().item()
-            assert d <= 1e-5 * (x[m].double().abs().max().item() + 1e-12), f"{what}: max diff {d}"
-
-    for (M, N, K) in [(600, 520, 352), (2236, 1024, 1024), (257, 384, 64), (1118, 4096, 320), (600, 520, 480), (300, 256, 288), (2236, 3072, 1024)]:
-        A, W = _rand((M, K), torch.bfloat16, 31, 0.3).to(dev), _rand((N, K), torch.bfloat16, 32, 0.3).to(dev)
-        b, R = _rand((N,), torch.float32, 33).to(dev), _rand((M, N), torch.float32, 34).to(dev)
-
-        def plain():
-            o32 = torch.full((M, N), float("nan"), device=dev); o16 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
-            ops.gemm(A, W, M=M, N=N, Kc=K, bias=b, residual=R, ldr=N, out32=o32, out16=o16)
-            return o32, o16
-
-        def split():
-            p = torch.full((3, M, N), float("nan"), device=dev)
-            ops.gemm(A, W, M=M, N=N, Kc=K, bias=b, residual=R, ldr=N, out32=p, split_k=3, c_split_stride=M * N)
-            return (p,)
-
-        def gelu():
-            o16 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
-            ops.gemm(A, W, M=M, N=N, Kc=K, bias=b, act=1, out16=o16)
-            return (o16,)
-
-        def transposed():
-            oT = torch.zeros((N, M), device=dev)
-            ops.gemm(A, W, M=M, N=N, Kc=K, bias=b, out32=oT, ldc=M, transpose_out=True)
-            return (oT,)
-
-        for name, f in (("plain", plain), ("split", split), ("transposed", transposed), ("gelu", gelu)):
-            if name == "split" and K < 3 * 64:
-                continue
-            for x, y in zip(run(4, f), run(tile, f)):
-                close(x, y, f"{name} {M}x{N}x{K} tile {tile}")
-        ref = A.double().cpu() @ W.double().cpu().T + b.double().cpu() + R.double().cpu()
-        _check(run(tile, plain)[0], ref, torch.bfloat16, K, f"plain {M}x{N}x{K} vs float64")
-
-    S1, Nn, K, Bx = 1118, 1024, 1440, 2     # batched operand with an output row offset, K ending in half a step (networks.py:196)
-    A, W = _rand((Bx * S1, K), torch.bfloat16, 38, 0.3).to(dev), _rand((Nn, K), torch.bfloat16, 39, 0.3).to(dev)
-    b = _rand((Nn,), torch.float32, 40).to(dev)
-
-    def batched():
-        o32 = torch.zeros((Bx * (S1 + 1), Nn), device=dev); o16 = torch.zeros((Bx * (S1 + 1), Nn), device=dev, dtype=torch.bfloat16)
-        ops.gemm(A, W, M=S1, N=Nn, Kc=K, lda=K, rowsA=S1, batch=Bx, a_bstride=S1 * K, c_bstride=S1 + 1, c_row_off=1, bias=b,
-                 out32=o32, out16=o16, ldc=Nn)
-        return o32, o16
-
-    for x, y in zip(run(4, batched), run(tile, batched)):
-        close(x, y, f"batched tile {tile}")
-
-    Mm, Hh2 = 600, 256                      # two sources concatenated along K (the skip Linear, networks.py:364)
-    buf = _rand((3, Mm, Hh2), torch.bfloat16, 43, 0.3).to(dev)
-    W2 = _rand((Hh2, 2 * Hh2), torch.bfloat16, 44, 0.3).to(dev)
-
-    def two_source():
-        o32 = torch.zeros((Mm, Hh2), device=dev); o16 = torch.zeros((Mm, Hh2), device=dev, dtype=torch.bfloat16)
-        ops.gemm(buf, W2, M=Mm, N=Hh2, Kc=Hh2, taps=2, lda=Hh2, rowsA=Mm, a_tap_stride=2 * Mm * Hh2, bias=b[:Hh2].contiguous(), out32=o32, out16=o16)
-        return o32, o16
-
-    for x, y in zip(run(4, two_source), run(tile, two_source)):
-        close(x, y, f"two-source tile {tile}")
-
-    for S in (1118, 333):                   # head-split epilogue, sequence boundary inside a tile at an even / odd position
-        B, Hh, D, K = 2, 4, 64, 128
-        Spad = (S + 63) // 64 * 64
-        A, W = _rand((B * S, K), torch.bfloat16, 35).to(dev), _rand((3 * Hh * D, K), torch.bfloat16, 36, 0.2).to(dev)
-        b = _rand((3 * Hh * D,), torch.float32, 37).to(dev)
-
-        def qkv():
-            q = torch.zeros((B, Hh, Spad, D), device=dev, dtype=torch.bfloat16); k = torch.zeros_like(q)
-            v = torch.zeros((B, Hh, D, Spad), device=dev, dtype=torch.bfloat16)
-            ops.gemm(A, W, M=B * S, N=3 * Hh * D, Kc=K, bias=b, qkv=dict(S=S, Spad=Spad, H=Hh, D=D, q=q, k=k, v=v))
-            return q, k, v
-
-        for x, y in zip(run(4, qkv), run(tile, qkv)):
-            close(x, y, f"qkv S={S} tile {tile}")
-
-
 def test_pingpong_selected_for_big_linear(dev):
     """The launcher's own choice on the Voicebox / LLM-prefill shapes is the ping-pong tile (kernel name in the plan's record is
     not visible from here, so check through the override-free result being bit-identical AND the documented rule's inputs)."""
@@ -440,7 +342,7 @@ def test_folded_layernorm_producer_and_consumers(dev, M, tile_env):
     from usdm_amd._lib import ACT_GELU, UsdmError
     H, I = 1024, 512
     bf = torch.bfloat16
-    for tile in (12, 13, 14, 15, 16):
+    for tile in (12, 13, 14):
         tile_env(tile)
         # ---- producer: x1 = A Wo^T + b + res, stats of x1
         A, Wo = _rand((M, H), bf, 41, 0.3).to(dev), _rand((H, H), bf, 42, 0.05).to(dev)

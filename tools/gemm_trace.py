@@ -73,15 +73,3 @@ e = ns(t[:, 5] - t0) / 1e3
 h, _ = np.histogram(e, bins=np.arange(0, e.max() + 1.0, 1.0))
 print("ends   per us bin:", h.tolist())
 
-# K-split tiles: shader-clock stamps inside K-step 8 of wave 0 (csrc/gemm.hip KTR)
-if hasattr(lib, "usdm_dbg_gemm_trace2"):
-    b2 = np.zeros(8192 * 8, dtype=np.uint64)
-    if lib.usdm_dbg_gemm_trace2(b2.ctypes.data_as(C.c_void_p), C.c_int(b2.size)) == 0:
-        k = b2.reshape(8192, 8)[:nwg].astype(np.int64)
-        if (k[:, 0] != 0).any():
-            seg = [("MFMAs + reads + DMA issued", k[:, 1] - k[:, 0]), ("LDS reads retired", k[:, 2] - k[:, 1]), ("DMA of step s+2 retired", k[:, 3] - k[:, 2]),
-                   ("barrier (arrive -> release)", k[:, 4] - k[:, 3]), ("whole step, shader cycles", k[:, 4] - k[:, 0])]
-            for nm, d in seg:
-                print(f"  K-step 8, wave 0: {nm:30s} median {np.median(d):8.0f} cyc  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}")
-            wall = (k[:, 6] - k[:, 5]) * 10.0
-            print(f"  K-step 8 wall {np.median(wall):.0f} ns -> shader clock {np.median((k[:, 4] - k[:, 0]) / np.maximum(wall, 1)):.2f} GHz")

@@ -37,18 +37,9 @@ kinds["skip (N1024 K2x1024 two sources)      *"] = skipf
 kinds["skip @tile14                          *"] = skipf
 kinds["wo @tile14                            *"] = kinds["wo   (N1024 K1024, +res f32 out)       "]
 wkey = ["qkv", "qkv", "wo", "w1", "w2", "w2", "w2", "wo", "skip", "skip", "wo"]
-# round 4: the K-split ping-pong tiles (15: 256x128, 16: 288x128) beside the launcher's own choice
 w2s3 = lambda W, p: ops.gemm(f16, W, M=R, N=H, Kc=I, bias=b1, residual=h32, ldr=H, out32=tmp32s, split_k=3, c_split_stride=R * H, plan=p)
-K_ = list(kinds.items())
-extra = [("w2*  (same, split-K 3 = the plan's)    *", w2s3, "w2")]
-for t in (12, 15, 16):
-    extra += [(f"qkv  head-split @tile{t}               *", K_[0][1], "qkv"), (f"qkv* plain bf16 @tile{t}               *", K_[1][1], "qkv"),
-              (f"w1   GELU @tile{t}                     *", K_[3][1], "w1"), (f"w2   split-K 3 @tile{t}                *", w2s3, "w2"),
-              (f"w2   unsplit @tile{t}                  *", K_[4][1], "w2")]
-extra += [(f"w1   GELU @tile13                     *", K_[3][1], "w1")]
-for n_, f_, k_ in extra:
-    kinds[n_] = f_
-    wkey.append(k_)
+kinds["w2*  (same, split-K 3 = the plan's)    *"] = w2s3
+wkey.append("w2")
 if _os.environ.get("VB_ONLY"):
     keep = [i for i, k in enumerate(kinds) if any(t in k for t in _os.environ["VB_ONLY"].split(","))]
     kinds = {k: v for i, (k, v) in enumerate(kinds.items()) if i in keep}

@@ -30,7 +30,6 @@ namespace {
 struct GemmDev {
   usdm_gemm_args a;
   int tiles_m, tiles_n;
-  int abl;   // usdm_gemm_args.tile_sel bits 8..: ablation switches of the K-split ping-pong loop for tools/ (1 no in-loop DMA, 2 no MFMA, 4 no fragment reads)
 };
 
 // compile-time loop: every accumulator index below is a constant, so nothing can fall into scratch
@@ -58,16 +57,8 @@ __device__ __forceinline__ float silu_mul(float g, float u, bool rbf) {
 // debugging aid (tools/gemm_trace.py): per-workgroup phase timestamps (100 MHz wall clock) + hardware ids
 __device__ unsigned long long g_gemm_trace[8192 * 8];
 #define TR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-// shader-clock stamps inside ONE K-step of the K-split loop (wave 0 of every workgroup, step KTR_STEP): barrier released, MFMAs +
-// reads + DMA issued, LDS reads retired, DMA of step s + 2 retired, next barrier released; + the 100 MHz clock at both ends
-__device__ unsigned long long g_gemm_trace2[8192 * 8];
-#define KTR_STEP 8
-#define KTR(i, s) do { if ((s) == KTR_STEP && threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace2[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define KTRW(i, s) do { if ((s) == KTR_STEP && threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace2[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define TR(i) do { } while (0)
-#define KTR(i, s) do { } while (0)
-#define KTRW(i, s) do { } while (0)
 #endif
 
 // bias of this thread's epilogue columns -> registers (SwiGLU: gate / up), per-column bias of the transposed epilogues -> LDS.
@@ -91,16 +82,12 @@ __device__ unsigned long long g_gemm_trace2[8192 * 8];
       for (int i = tid; i < BN; i += NTH) sb[i] = (bias && n0 + i < a.N) ? bias[gcol + n0 + i] : 0.f;                       \
   } while (0)
 
-template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2, bool PP = false, bool KSP = false>
+template <typename T, int BM, int BN, int NWM, int NWN, bool DMA, int NST = 2, int NCH = 2, bool PP = false>
 // NWM x NWN waves over the BM x BN tile; DMA: global->LDS direct with NST LDS stages of NCH 64-byte chunks each;
-// PP: the 8-wave ping-pong K loop (two wave groups one barrier apart, see below);
-// KSP (with PP): TWO groups of NWM x NWN waves; group g multiplies K half g of every 64-deep step over the WHOLE tile ("K-split
-// ping-pong", round 4) and the two accumulator sets are exchanged through LDS before the epilogue
-__global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(const GemmDev g) {
+// PP: the 8-wave ping-pong K loop (two wave groups one barrier apart, see below)
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const usdm_gemm_args& a = g.a;
-  constexpr int WPG = NWM * NWN;               // waves per group (one group unless KSP)
-  constexpr int NGRP = KSP ? 2 : 1;
-  constexpr int NTH = WPG * NGRP * 64;
+  constexpr int NTH = NWM * NWN * 64;
   constexpr int WTM = BM / NWM, WTN = BN / NWN;  // wave tile
   constexpr int ES = sizeof(T);       // element size
   constexpr int CE = 64 / ES;         // elements per chunk
@@ -124,8 +111,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     g_gemm_trace[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
 #endif
   const int lane = tid & 63, wave = tid >> 6;
-  const int wq = wave % WPG;                   // position inside the wave group
-  const int wm = wq / NWN, wn = wq % NWN;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 15, lc = lane >> 4;
 
   // tile mapping: blocks that share an XCD (blockIdx % 8) get consecutive tiles; N is walked first
@@ -208,14 +194,14 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   const float* bias = ksi == 0 ? a.bias : nullptr;   // bias and residual belong to split 0
   const bool swiglu = a.act == USDM_ACT_SWIGLU;
   constexpr int C4 = BN / 4, RPI = NTH / C4, NIT = BM / RPI;
-  const int ec0 = (tid % C4) * 4;
+  const int ec = (tid % C4) * 4, er = tid / C4;
   float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};   // SwiGLU: gate / up
   // outputs whose fast axis is m (transpose_out, V^T tiles of the head-split epilogue) go through a transposed LDS tile;
   // their per-column bias is staged in LDS (visible after the K loop's barriers)
   const bool tr_mode = a.transpose_out != 0 || (a.epi == USDM_EPI_QKV_HEADS && n0 >= 2 * a.qkv_H * a.qkv_D);
   float* sb = (float*)(smem + SMEM);
   float* rowst = sb + BN;   // [BM][2], ping-pong tiles only
-  if constexpr (!PP) USDM_GEMM_FETCH_BIAS(tid, ec0);   // the ping-pong variants fetch it behind their first LDS-DMA instead
+  if constexpr (!PP) USDM_GEMM_FETCH_BIAS(tid, ec);   // the ping-pong variants fetch it behind their first LDS-DMA instead
 
   f32x4 acc[TM][TN];
   static_for<TM>([&](auto I) { static_for<TN>([&](auto J) { acc[I][J] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
@@ -226,7 +212,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   // Per-lane offsets of the wave-instructions this wave issues are loop invariants: only the chunk column
   // (+64 B per chunk) and, for multi-tap operands, the row shift change from K-step to K-step.
   constexpr int QA = BM / 16 * NCH, QB = BN / 16 * NCH;  // wave-instructions per operand per K-step
-  constexpr int NWV = WPG * NGRP;
+  constexpr int NWV = NWM * NWN;
   constexpr int NIA = (QA + NWV - 1) / NWV, NIB = (QB + NWV - 1) / NWV;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   // The LDS-DMA variants serve single-tap operands only (Linear layers: no per-tap row remap; the launcher routes multi-tap
@@ -415,128 +401,6 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     const int grp = wv >> 2;
     const int nst = nks;                                   // K-steps (NCH = 2 chunks each)
     const bool odd_tail = ((q_hi - q_lo) & 1) != 0;        // the last step has only its first half
-   if constexpr (KSP) {
-    // ---- K-split tiles, ONE barrier per K-step (round 4).  Measured on the ping-pong loop below (profiles/r04_gemm_ablation.txt):
-    // its skeleton (two barriers per phase, nothing else) costs 3.8 us of a 13.3 us K loop, its fragment reads 3.2 us (the LDS array
-    // delivers ~200 B/clk: the port is NOT the limit, contrary to the round-3 reading), its MFMAs 6.4 us - and the three ADD, in the
-    // 64 x 64-wave-tile form and in a two-group K-split form alike: a wave's read -> barrier -> multiply -> barrier chain is serial
-    // and the partner's work overlaps far less than the schedule suggests.  So the chain is cut instead of re-balanced:
-    //   * the 8 waves are two groups of NWM x NWN waves that BOTH cover the whole BM x BN tile (wave tile 128 x 64 / 144 x 64:
-    //     12 / 13 fragment reads per 32 / 36 MFMAs); group g multiplies K half g of every 64-deep step;
-    //   * the fragments of step s + 1 are read WHILE step s is multiplied, by the same wave: A fragment i is reloaded right after
-    //     its four MFMAs (single-buffered: 28 MFMAs lie between the reload and the next use), the four W fragments alternate
-    //     between two register sets (the step loop is unrolled by two); nothing waits for LDS inside a step;
-    //   * the LDS-DMA of step s + 3 is issued between the MFMAs of step s (one instruction per row block: the other wave of the
-    //     SIMD keeps the matrix pipe busy meanwhile) into the slot whose fragments this step already holds in registers: three
-    //     slots give a prefetch distance of TWO steps (the ping-pong loop: one);
-    //   * one s_barrier per step, all eight waves in phase.  Before it every wave has retired its fragment reads (lgkmcnt(0):
-    //     WAR for the slot refilled next) and the DMA of step s + 2 (counted vmcnt: RAW for the reads of the next step).
-    // A K that ends in half a step leaves group 1's half of the last step zero-filled (the DMA's range check): it adds zeros.
-    // The two groups' accumulators are summed after the loop (each wave keeps the columns [grp * WTN / 2, +WTN / 2) of its wave
-    // tile): every output is (sum over even K halves) + (sum over odd K halves) - a fixed order, but not the order of the other
-    // tiles (tests/test_gemm_gpu.py::test_ksplit_pingpong_tiles compares against them at f32 rounding level, not bit for bit).
-    TR(1);
-    // steps past the end are issued as placeholders (2) and their fragments read as garbage that nothing uses: every step of the
-    // loop is then the SAME straight-line code (no run-time tests inside: at a join the compiler's wait-count pass waits for the LDS
-    // in front of every MFMA group, the serialisation this loop exists to remove)
-    auto chk_of = [&](int step) -> int { return step >= nst ? 2 : ((odd_tail && step == nst - 1) ? 1 : 0); };
-#pragma unroll
-    for (int p = 0; p < 3; ++p) pp_issue(p, p, 2, chk_of(p));
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    TR(2);
-    // Fragment addresses: ONE per-lane base per operand (this group's K half of row block 0 of the wave tile); row block i lies
-    // 16 rows = 2048 bytes further on (the swizzle only looks at row bits 1..2 and the K half), so every ds_read_b128 below is
-    // base + an immediate.
-    unsigned fbaseA, fbaseK, fbaseS;           // A; W blocks this group keeps; W blocks it sends after the loop
-    {
-      const int r = wm * WTM + lr;
-      fbaseA = ((r >> 3) * 1024 + (r & 7) * 128 + ((lc ^ ((r >> 1) & 7)) << 4)) ^ (grp << 6);
-      // column blocks of the wave tile in the order (kept half, sent half): group g keeps blocks [g * TN / 2, +TN / 2), so that
-      // acc[I][J < TN / 2] is the kept half in BOTH groups and the exchange below moves no registers around
-      const int rk = wn * WTN + grp * (WTN / 2) + lr, rs = wn * WTN + (1 - grp) * (WTN / 2) + lr;
-      fbaseK = (BM * 128 + (rk >> 3) * 1024 + (rk & 7) * 128 + ((lc ^ ((rk >> 1) & 7)) << 4)) ^ (grp << 6);
-      fbaseS = (BM * 128 + (rs >> 3) * 1024 + (rs & 7) * 128 + ((lc ^ ((rs >> 1) & 7)) << 4)) ^ (grp << 6);
-    }
-    u32x4 fa[TM], fb0[TN], fb1[TN];
-    static_assert(TM >= TN && TM > NPW, "rolling schedule: one W fragment / one DMA instruction behind each of the first row blocks");
-    auto rd_b = [&](u32x4* fb, int slot, int j) {
-      fb[j] = *(const u32x4*)(smem + slot * STAGE + (j < TN / 2 ? fbaseK + j * 2048 : fbaseS + (j - TN / 2) * 2048));
-    };
-    auto rd_a = [&](int slot, int i) { fa[i] = *(const u32x4*)(smem + slot * STAGE + fbaseA + i * 2048); };
-    // step 0's fragments, plainly
-#pragma unroll
-    for (int j = 0; j < TN; ++j) rd_b(fb0, 0, j);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) rd_a(0, i);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                            // lgkmcnt(0)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                     // step 1 landed (step 2 may be in flight)
-    // One K-step: multiply step s out of (fa, fbc), read step s + 1 into (fa, fbn), issue the DMA of step s + 3 into slot s % 3
-    auto kstep = [&](const int s, const int sl, const int sl1, u32x4* fbc, u32x4* fbn) __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      KTR(4, s - 1); KTRW(6, s - 1);
-      KTR(0, s); KTRW(5, s);
-      const int chk = chk_of(s + 3);
-      unsigned kcA, kcW;
-      pp_cols(s + 3, kcA, kcW);
-      static_for<TM>([&](auto I) {
-        static_for<TN>([&](auto J) {
-          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[I]), __builtin_bit_cast(bf16x8, fbc[J]),
-                                                              acc[I][J], 0, 0, 0);
-        });
-        rd_a(sl1, I);
-        if constexpr (I < TN) rd_b(fbn, sl1, I);
-        // LDS-DMA issue, STAGGERED between the two waves of a SIMD: an issue stalls its wave for ~56 cycles (stamps: with both
-        // waves issuing behind the same row blocks the MFMA section took 1360 cycles instead of 1024); group 0 issues behind its
-        // first row blocks, group 1 behind its last ones, so the other wave's MFMAs fill the pipe meanwhile
-        constexpr int NI = PNF + (PLA ? 1 : 0), NB2 = (NI + 1) / 2;   // instructions per wave and step; row blocks that carry two
-        static_assert(2 * NB2 <= TM, "the two groups' issue windows must not overlap");
-        if constexpr (I < NB2) {
-          if (grp == 0) { pp_issue(sl, s + 3, 2, chk, 2 * I, kcA, kcW); if constexpr (2 * I + 1 < NI) pp_issue(sl, s + 3, 2, chk, 2 * I + 1, kcA, kcW); }
-        }
-        if constexpr (I >= TM - NB2) {
-          constexpr int q = I - (TM - NB2);
-          if (grp == 1) { pp_issue(sl, s + 3, 2, chk, 2 * q, kcA, kcW); if constexpr (2 * q + 1 < NI) pp_issue(sl, s + 3, 2, chk, 2 * q + 1, kcA, kcW); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      KTR(1, s);
-      __builtin_amdgcn_s_waitcnt(0xC07F);                                          // lgkmcnt(0): this step's fragment reads retired
-      KTR(2, s);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                   // step s + 2 landed (s + 3 in flight)
-      KTR(3, s);
-    };
-    {
-      int s = 0, sl = 0, sl1 = 1;
-      auto adv = [&]() { ++s; if (++sl == 3) sl = 0; if (++sl1 == 3) sl1 = 0; };
-#pragma unroll 1
-      for (; s + 1 < nst;) {
-        kstep(s, sl, sl1, fb0, fb1); adv();
-        kstep(s, sl, sl1, fb1, fb0); adv();
-      }
-      if (s < nst) kstep(s, sl, sl1, fb0, fb1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the placeholder issues of the last steps (they write zeros into the slots)
-    __syncthreads();
-    // ---- exchange: every wave hands the half of its accumulators it does not keep (columns of the OTHER group) to the wave with
-    // the same wave tile in the other group (wave ^ 4) and adds what it receives.  [wave][fragment][lane] x 16 B: conflict-free.
-    {
-      constexpr int TNH = TN / 2;
-      static_assert(TN % 2 == 0 && (size_t)NWV * TM * TNH * 1024 <= (size_t)NST * STAGE, "K-split exchange buffer");
-      f32x4* xb = (f32x4*)smem;
-      const int xl = tid & 63;
-      static_for<TM>([&](auto I) {
-        static_for<TNH>([&](auto J) { xb[(wv * (TM * TNH) + I * TNH + J) * 64 + xl] = acc[I][J + TNH]; });
-      });
-      __syncthreads();
-      static_for<TM>([&](auto I) {
-        static_for<TNH>([&](auto J) { acc[I][J] += xb[((wv ^ 4) * (TM * TNH) + I * TNH + J) * 64 + xl]; });
-      });
-      __syncthreads();                       // the exchange buffer becomes the epilogue tile
-    }
-   } else {
     TR(1);
     if (nst > 0) pp_issue(0, 0, 2, nst == 1 && odd_tail);
     if (nst > 1) pp_issue(1, 1, 2, nst == 2 && odd_tail);
@@ -544,7 +408,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     TR(2);
-    USDM_GEMM_FETCH_BIAS(tid, ec0);
+    USDM_GEMM_FETCH_BIAS(tid, ec);
     if (grp == 1) __builtin_amdgcn_s_barrier();
     // fragment byte offsets of this lane inside a slot, for either K half (loop invariants)
     unsigned foA[2][TM], foB[2][TN];
@@ -608,7 +472,6 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __syncthreads();
-   }
   } else if constexpr (DMA) {
     // two LDS stages; step ks+1 streams into the idle stage by LDS-DMA while step ks is multiplied
     // NST LDS stages: the DMA of K-step ks+NST-1 is issued while step ks is multiplied; a counted vmcnt leaves the
@@ -675,16 +538,6 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   // before the K loop (bv/bu above) and residual rows are fetched a batch at a time ahead of their use: a load
   // inside the store loop costs a full memory latency per iteration (measured: 14 us of a 33 us 128x128 tile).
   TR(3);
-  // Thread coordinates of the epilogue, derived from a copy of the thread id the compiler cannot see through (K-split tiles): what
-  // the epilogue needs is then computed HERE and does not sit in registers across the K loop, where 128 accumulators + 48 fragment
-  // registers leave no room for it (the first build spilled the loop's DMA offsets and waited vmcnt(0) on their reloads).
-  int etid = threadIdx.x;
-  if constexpr (KSP) asm volatile("" : "+v"(etid));
-  const int elane = etid & 63, ewave = etid >> 6;
-  const int ewq = ewave % WPG, ewm = ewq / NWN, ewn = ewq % NWN;
-  const int elr = elane & 15, elc = elane >> 4;
-  const int ec = (etid % C4) * 4, er = etid / C4;
-  if constexpr (KSP) USDM_GEMM_FETCH_BIAS(etid, ec);
   if constexpr (PP) {
     // folded LayerNorm: (rstd, rstd * mean) of this tile's rows from the producer's per-tile partial sums.  Requested HERE, after
     // the K loop (in the prologue the loads' wait would sit in front of the first K-step): the latency runs under the accumulator
@@ -694,7 +547,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
       // variance never goes through sum(x^2) - mean^2 (which loses |mean| / sigma squared in relative accuracy)
       const float ncol = (float)(a.ln_C / a.ln_nt), inv_ncol = 1.0f / ncol;
       bool unsafe = false;
-      for (int i = etid; i < BM; i += NTH) {
+      for (int i = tid; i < BM; i += NTH) {
         const int m = m0 + i;
         float s1 = 0.f, m2 = 0.f;
         float mean = 0.f;
@@ -721,29 +574,26 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   const bool is_qkv = a.epi == USDM_EPI_QKV_HEADS;
 
   constexpr bool TR_OK = NTH % (BM / 4) == 0 && BN % (NTH / (BM / 4)) == 0;   // tile geometries the transposed store loops cover
-  // accumulator columns a ewave holds at this point: its whole ewave tile, or - K-split tiles - the half it kept in the exchange
-  constexpr int TNE = KSP ? TN / 2 : TN, WTNE = KSP ? WTN / 2 : WTN;
-  const int wne = KSP ? ewn * 2 + (ewave / WPG) : ewn;
   if (tr_mode) {
     if constexpr (!TR_OK) return;   // (the launcher routes transposed outputs to the other tiles: usdm_gemm, sel == 13)
-    // ---- transposed mode: the accumulator fragment of a elane is 4 consecutive rows of one column, i.e. one float4 of the
+    // ---- transposed mode: the accumulator fragment of a lane is 4 consecutive rows of one column, i.e. one float4 of the
     // transposed tile; the store loop then reads float4s along m without bank conflicts (a strided read of the row-major
     // tile was 8-way conflicted: 10 us per 128x128 V tile)
     static_for<TM>([&](auto I) {
-      static_for<TNE>([&](auto J) {
-        const int col = wne * WTNE + J * 16 + elr;
-        const int row = ewm * WTM + I * 16 + elc * 4;
+      static_for<TN>([&](auto J) {
+        const int col = wn * WTN + J * 16 + lr;
+        const int row = wm * WTM + I * 16 + lc * 4;
         *(float4*)(ct + col * CSTT + row) = make_float4(acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]);
       });
     });
     __syncthreads();
     TR(4);
     if (is_qkv) {
-      // V^T[b][h][d][s]: elane = 4 consecutive tokens of one feature, a ewave = 256 tokens of it -> dense 8-byte-per-elane stores
-      // (4 bytes per elane took 5.5 us per 256x128 tile against 2.8 us for the Q / K tiles).  Lanes whose 4 tokens straddle a
+      // V^T[b][h][d][s]: lane = 4 consecutive tokens of one feature, a wave = 256 tokens of it -> dense 8-byte-per-lane stores
+      // (4 bytes per lane took 5.5 us per 256x128 tile against 2.8 us for the Q / K tiles).  Lanes whose 4 tokens straddle a
       // sequence end, the matrix end or an odd position store token by token.
       constexpr int R4V = BM / 4, CPI4 = NTH / R4V, NITV = BN / CPI4;
-      const int r4 = (etid % R4V) * 4, c0v = etid / R4V;
+      const int r4 = (tid % R4V) * 4, c0v = tid / R4V;
       const int m = m0 + r4;
       const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
       if (mv > 0) {
@@ -795,7 +645,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
       return;
     }
     constexpr int R4 = BM / 4, CPI = NTH / R4, NIT2 = BN / CPI;
-    const int r4 = (etid % R4) * 4, c0 = etid / R4;
+    const int r4 = (tid % R4) * 4, c0 = tid / R4;
     const int m = m0 + r4;
     const int mv = (a.M - m) < 4 ? (a.M - m) : 4;
     if (mv > 0) {
@@ -840,9 +690,9 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   }
 
   static_for<TM>([&](auto I) {
-    static_for<TNE>([&](auto J) {
-      const int col = wne * WTNE + J * 16 + elr;
-      const int row = ewm * WTM + I * 16 + elc * 4;
+    static_for<TN>([&](auto J) {
+      const int col = wn * WTN + J * 16 + lr;
+      const int row = wm * WTM + I * 16 + lc * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ct[(row + e) * CST + col] = acc[I][J][e];
     });
@@ -853,7 +703,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
   if (swiglu) {
     // column tiles (2p, 2p+1) of 16 hold gate / up of the same 16 output features
     constexpr int OC4 = BN / 8, RPS = NTH / OC4, NIS = BM / RPS;
-    const int c4 = (etid % OC4) * 4, rr = etid / OC4;
+    const int c4 = (tid % OC4) * 4, rr = tid / OC4;
     const int cg = (c4 >> 4) * 32 + (c4 & 15);   // gate column inside the tile
     const int ngate = n0 + cg;
     if (ngate < a.N) {
@@ -1035,8 +885,8 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
             for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
           }
         }
-        if (stp) {   // the C4 threads that share this row are one half (BN = 128) or one DPP row (BN = 64) of a ewave: reduce, one 8-byte store per row and tile
-          // (sum, M2 about the tile mean) of this tile's BN columns of the row: two dependent elane reductions instead of one,
+        if (stp) {   // the C4 threads that share this row are one half (BN = 128) or one DPP row (BN = 64) of a wave: reduce, one 8-byte store per row and tile
+          // (sum, M2 about the tile mean) of this tile's BN columns of the row: two dependent lane reductions instead of one,
           // but no sum of raw squares (see the consumer)
           const float t1 = (v[0] + v[1]) + (v[2] + v[3]);
           const float s1 = C4 == 32 ? half_sum(t1) : row16_sum(t1);
@@ -1044,7 +894,7 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
           const float d0 = v[0] - mt, d1 = v[1] - mt, d2 = v[2] - mt, d3 = v[3] - mt;
           const float t2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
           const float s2 = C4 == 32 ? half_sum(t2) : row16_sum(t2);
-          if ((etid & (C4 - 1)) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
+          if ((tid & (C4 - 1)) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
         }
         const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
         if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1083,15 +933,14 @@ __global__ __launch_bounds__(NWM * NWN * 64 * (KSP ? 2 : 1)) void gemm_kernel(co
 
 #undef USDM_GEMM_FETCH_BIAS
 
-template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2, bool PP = false, bool KSP = false>
+template <typename T, int BM, int BN, int NWM = 2, int NWN = 2, bool DMA = false, int NST = 2, int NCH = 2, bool PP = false>
 int launch(const usdm_gemm_args& a, hipStream_t st) {
   GemmDev g;
   g.a = a;
   g.tiles_m = cdiv(a.M, BM);
   g.tiles_n = cdiv(a.N, BN);
-  g.abl = a.tile_sel > 0 ? (a.tile_sel >> 8) : 0;
   dim3 grid(g.tiles_m * g.tiles_n, 1, a.groups * a.batch * (a.split_k > 1 ? a.split_k : 1));
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH, PP, KSP>), grid, dim3(NWM * NWN * 64 * (KSP ? 2 : 1)), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, NWM, NWN, DMA, NST, NCH, PP>), grid, dim3(NWM * NWN * 64), 0, st, g);
   USDM_LAUNCH_CHECK();
   return 0;
 }
@@ -1101,9 +950,6 @@ int launch(const usdm_gemm_args& a, hipStream_t st) {
 #ifdef USDM_GEMM_TRACE
 extern "C" int usdm_dbg_gemm_trace(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * n);
-}
-extern "C" int usdm_dbg_gemm_trace2(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace2), sizeof(unsigned long long) * n);
 }
 #endif
 
@@ -1184,9 +1030,8 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (a.tile_sel > 0) sel = (a.tile_sel & 0xff) - 1;   // benchmarking / test override (usdm_gemm_args.tile_sel; ops.gemm fills it from USDM_GEMM_TILE)
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tiles have row-major epilogues only
-  if (sel == 16 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 15;
   if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
-    USDM_CHECK_ARG(sel >= 12 && sel <= 16 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
+    USDM_CHECK_ARG(sel >= 12 && sel <= 14 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
                        a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
                    "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
     USDM_CHECK_ARG(!a.stats_out || (a.act == USDM_ACT_NONE && a.split_k <= 1), "usdm_gemm: stats_out needs a plain, unsplit epilogue");
@@ -1212,8 +1057,6 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 12) return launch<bf16_t, 256, 128, 4, 2, true, 3, 2, true>(a, st);   // 8-wave ping-pong loop, one workgroup per CU
     if (sel == 13) return launch<bf16_t, 288, 128, 2, 4, true, 3, 2, true>(a, st);   // row-major epilogues only
     if (sel == 14) return launch<bf16_t, 128, 128, 4, 2, true, 3, 2, true>(a, st);   // the same loop on a 128x128 tile (wave tile 32x64)
-    if (sel == 15) return launch<bf16_t, 256, 128, 2, 2, true, 3, 2, true, true>(a, st);   // K-split ping-pong: 2 groups x (2 x 2) waves, wave tile 128x64
-    if (sel == 16) return launch<bf16_t, 288, 128, 2, 2, true, 3, 2, true, true>(a, st);   // ... wave tile 144x64; row-major epilogues only
     if (sel == 0) return launch<bf16_t, 128, 128>(a, st);
     if (sel == 1) return launch<bf16_t, 128, 64>(a, st);
     return launch<bf16_t, 64, 64>(a, st);

@@ -105,7 +105,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
             a.ln_guard, a.ln_guard_ratio = _ptr(ln["guard"]), float(ln["guard_ratio"])
     tile = os.environ.get("USDM_GEMM_TILE")      # benchmarks / tile-equivalence tests: the library itself reads no environment
     if tile is not None:
-        a.tile_sel = int(tile) + 1 + (int(os.environ.get("USDM_GEMM_ABL", "0")) << 8)      # (ablation switches of the K-split loop, tools/ only)
+        a.tile_sel = int(tile) + 1
     if qkv is not None:
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]
