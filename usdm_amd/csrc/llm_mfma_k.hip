@@ -40,7 +40,6 @@ constexpr int LDS_BYTES = RED_BYTES + GAM_FLOATS * 4 + MW * 16 * 4 + 64 * 4 + 2 
 struct MfmaDev {
   usdm_gemv_batch_args ba;
   int ntiles, rt, cpw, nchunks, grid, nout;
-  int dbg_contig;   // form 2 (timing experiment only, WRONG results): every load instruction reads 1 KiB of one row instead of 16 rows x 64 B
 };
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 w, u32x4 x, f32x4 acc) {
@@ -136,19 +135,9 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
       const int line = (int)((blockIdx.x * MW + wave) % (unsigned)(K / 32 - 16));
       return (const u32x4*)a.x + line * 4 + (lane & 3);
     }
-    if (d.dbg_contig) {
-      // form 2, a TIMING EXPERIMENT with wrong results: the same bytes per tile and wave read row-contiguously - load instruction c
-      // reads 1 KiB of row (first row of the tile + c % 16), all inside the matrix (N >= 16; chunk offsets wrap inside the K slice)
-      const int row0 = min(max(t, 0) * 16, a.N - 16);
-      return (const u32x4*)(Wb + (int64_t)row0 * a.ldw + (int64_t)kc0 * 32 + lane * 8);
-    }
     return (const u32x4*)(Wb + (int64_t)row * a.ldw + (int64_t)kc0 * 32 + 8 * g);
   };
   auto wload = [&](const u32x4* base, int c) -> u32x4 {
-    if (d.dbg_contig) {
-      const int kblk = cpw >= 16 ? (c >> 4) % (cpw >> 4) : 0;                 // 512-element blocks inside the wave's K slice
-      return __builtin_nontemporal_load((const u32x4*)((const bf16_t*)base + (int64_t)(c & 15) * a.ldw + kblk * 512));
-    }
     return __builtin_nontemporal_load(base + c * 4);
   };
   const u32x4* xbase = (const u32x4*)((const bf16_t*)a.x + (int64_t)min(r16, nb - 1) * d.ba.x_bs + (int64_t)kc0 * 32 + 8 * g);
@@ -456,7 +445,6 @@ int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   MfmaDev d;
   d.ba = *pa;
   d.nchunks = a.K / 32;
-  d.dbg_contig = (pa->form == 2 && a.N >= 16 && d.nchunks / MW >= 16) ? 1 : 0;      // (needs K slices of >= 512 elements)
   d.cpw = cdiv(d.nchunks, MW);
   const bool hold = d.cpw <= CH;
   USDM_CHECK_ARG(!a.norm_w || (hold && a.K <= GAM_FLOATS && a.K % 4 == 0), "usdm_gemv_batch (matrix-core form): the fused RMSNorm needs K <= 4096");
