@@ -29,13 +29,16 @@
 namespace {
 constexpr int MW = 8;     // waves per workgroup (two per SIMD: 256 registers each, spent on loads in flight)
 constexpr int CH = 16;    // K chunks of 32 a wave can hold activations for (K <= MW * CH * 32 = 4096)
-constexpr int MTG = 16;   // tiles per reduction group (LDS: MTG x MW waves x 1 KiB)
+constexpr int MTG_DEF = 16;   // tiles per reduction group (LDS: MTG x MW waves x 1 KiB)
+constexpr int MTG_TRL = 8;    // ... of the transposed-load variant (its LDS also holds 8 KiB of transposition buffer per wave)
 #ifndef USDM_MFMA_NO_ASM
 #define USDM_MFMA_NO_ASM 0   // 1: the compiler-scheduled stream everywhere (debugging)
 #endif
-constexpr int RED_BYTES = MTG * MW * 64 * 16;
 constexpr int GAM_FLOATS = 4096;
-constexpr int LDS_BYTES = RED_BYTES + GAM_FLOATS * 4 + MW * 16 * 4 + 64 * 4 + 2 * MTG * 16 * 4;
+constexpr int TAIL_BYTES = GAM_FLOATS * 4 + MW * 16 * 4 + 64 * 4 + 2 * MTG_DEF * 16 * 4;       // gam, ssum, tl, sv, si
+constexpr int LDS_BYTES = MTG_DEF * MW * 1024 + TAIL_BYTES;
+constexpr int TB_OFF = MTG_TRL * MW * 1024 + TAIL_BYTES;                                        // transposition buffers of the TRL variant
+constexpr int LDS_BYTES_TRL = TB_OFF + MW * 8192;
 
 struct MfmaDev {
   usdm_gemv_batch_args ba;
@@ -63,17 +66,24 @@ __device__ __forceinline__ void wait_mfma_asm(f32x4& acc, const u32x4& w, const 
     asm volatile("s_waitcnt vmcnt(%3)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x), "n"(WAIT));
 }
 
-template <bool HOLD, int CPWT>
+// TRL ("transposed loads", K = 4096 only): the weights are loaded ROW-CONTIGUOUSLY - a load instruction reads 512 bytes of each of
+// two rows, the pattern the batch-1 kernel streams at 5.9 TB/s - and re-cut into MFMA fragments through a private 8 KiB LDS buffer
+// per wave (ds_write_b128 by rows, ds_read_b128 by fragments, XOR swizzle piece ^ row: conflict-free both ways).  The fragment-shaped
+// loads of the other variants (16 rows x 64 bytes per instruction) measured 4.4 TB/s at best: 64-byte requests and a DRAM page
+// visit per 64 - 128 bytes.  LDS traffic: 2 x 56 MB per CU and step against 56 MB of HBM traffic at a tenth of the LDS rate.
+template <bool HOLD, int CPWT, bool TRL>
 __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   const usdm_gemv_args& a = d.ba.g;
   const int cpw = CPWT > 0 ? CPWT : d.cpw;
+  constexpr int MTG = TRL ? MTG_TRL : MTG_DEF;             // tiles per reduction group
+  constexpr int RED_BYTES = MTG * MW * 64 * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* red = (f32x4*)smem;                               // [MTG][MW][64] partial D fragments
   float* gam = (float*)(smem + RED_BYTES);                 // [K <= 4096] RMSNorm weight
   float* ssum = gam + GAM_FLOATS;                          // [MW][16] partial sums of squares
   int* tl = (int*)(ssum + MW * 16);                        // [MTG] tile ids of the group being reduced
   float* sv = (float*)(tl + 64);                           // lm_head: [MW][16] best value / index per reducing wave and sequence
-  int* si = (int*)(sv + MTG * 16);
+  int* si = (int*)(sv + MTG_DEF * 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
@@ -161,22 +171,66 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   // refilled with item j + 24 as soon as it has been multiplied; the stream loop below is unrolled over three tiles so that slot and
   // chunk indices are constants.  Otherwise (STREAM): CH (weight, activation) pairs.
   constexpr int RS = 24;
-  u32x4 ring[HOLD ? RS : CH];
+  u32x4 ring[TRL ? 1 : (HOLD ? RS : CH)];
   u32x4 rx[HOLD ? 1 : CH];
-  int t0 = next_tile(rem_ld), t1 = -1, t2 = -1;             // tile being multiplied, the next two (loads in flight / to be issued)
+  // ---- TRL: NR = 3 units of 8 row-contiguous loads (16 rows x 512 bytes = 8 chunks of this wave's K slice) = one and a half tiles in
+  // flight (24 KiB per wave; four units next to the 16 held activation fragments spill)
+  constexpr int NR = HOLD ? 3 : 2;                          // (streamed activations: 16 loads per unit, two units = 32 KiB per wave)
+  u32x4 U[TRL ? NR : 1][8];
+  u32x4 X[(TRL && !HOLD) ? NR : 1][8];                     // streamed activations of the same units (K > 4096)
+  const int lrow = lane >> 5, lp = lane & 31;              // row (of a pair) and 16-byte piece this lane loads
+  auto unit_ptr = [&](int t, int sub, int i) -> const u32x4* {
+    if (t < 0) return (const u32x4*)a.x + ((blockIdx.x * MW + wave) & 7) * 4 + (lane & 3) + i * 32;      // placeholder: 64 B of x (see wbase)
+    const int r = 2 * i + lrow;                            // A-row of the tile
+    int row;
+    if (glu) {
+      const int f = min(t * 8 + (r & 7), d.nout - 1);
+      row = (f >> 4) * 32 + (f & 15) + (r >= 8 ? 16 : 0);
+    } else {
+      row = min(t * d.rt + r, a.N - 1);
+    }
+    return (const u32x4*)(Wb + (int64_t)row * a.ldw + (int64_t)wave * (cpw * 32) + sub * 256 + lp * 8);
+  };
+  int t0 = TRL ? -1 : next_tile(rem_ld), t1 = -1, t2 = -1;  // tile being multiplied, the next two (loads in flight / to be issued)
   const u32x4* wp0 = wbase(t0);
   const u32x4* wp1 = wp0;
   const u32x4* wp2 = wp0;
-  constexpr bool ASM_STREAM = HOLD && CPWT == CH && !USDM_MFMA_NO_ASM;     // hand-counted loads (see the stream loop)
+  constexpr bool ASM_STREAM = HOLD && CPWT == CH && !USDM_MFMA_NO_ASM && !TRL;     // hand-counted loads (see the stream loop)
+  int ua = -1, ub = -1, uc = -1;                            // TRL: the tile being multiplied and the next two
+  // TRL with streamed activations (K = 14336): units are numbered through the tiles, 7 per tile; (lt, ls) = the next unit to load
+  int lt = -1, ls = 0;
+  constexpr int UPT = CPWT / 8;                             // units per tile and wave
+  auto ld_unit_x = [&](auto SLOT, int t, int sub) __attribute__((always_inline)) {
+    constexpr int q = decltype(SLOT)::value;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_nt_asm(U[q][i], unit_ptr(t, sub, i));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ld_nt_asm(X[q][c], xbase + (sub * 8 + c) * 4);
+  };
+  auto adv_unit = [&]() { if (++ls == UPT) { ls = 0; lt = next_tile(rem_ld); } };
+  if constexpr (TRL && !HOLD) {
+    lt = next_tile(rem_ld);
+    ld_unit_x(std::integral_constant<int, 0>{}, lt, ls); adv_unit();
+    ld_unit_x(std::integral_constant<int, 1>{}, lt, ls); adv_unit();
+  }
+  if constexpr (TRL && HOLD) {
+    ua = next_tile(rem_ld); ub = next_tile(rem_ld); uc = next_tile(rem_ld);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_nt_asm(U[0][i], unit_ptr(ua, 0, i));      // units 0, 1, 2 = (tile a, half 0), (a, 1), (b, 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_nt_asm(U[1][i], unit_ptr(ua, 1, i));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_nt_asm(U[2][i], unit_ptr(ub, 0, i));
+  }
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    if (c < cpw) {
+    if (c < cpw && !TRL) {
       if constexpr (ASM_STREAM) ld_nt_asm(ring[c], wp0 + c * 4);
       else ring[c] = wload(wp0, c);
       if constexpr (!HOLD) rx[c] = xload(c);
     }
   }
-  if constexpr (HOLD) {
+  if constexpr (HOLD && !TRL) {
     t1 = next_tile(rem_ld);
     wp1 = wbase(t1);
 #pragma unroll
@@ -321,7 +375,87 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   };
 
   // ---- stream
-  if constexpr (HOLD) {
+  if constexpr (TRL && !HOLD) {
+    char* tb = smem + TB_OFF + wave * 8192;
+    int ct = next_tile(rem_cp), cs = 0;                     // the unit being multiplied
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // one unit: its 16 loads have landed (the 32 younger ones stay in flight), rows -> LDS, fragments <- LDS, 8 MFMAs against the
+    // unit's own activation fragments, then the slot is refilled with the unit three further on
+    auto unit = [&](auto SLOT) __attribute__((always_inline)) -> bool {
+      constexpr int q = decltype(SLOT)::value;
+      if (ct < 0) return false;
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(U[q][0]), "+v"(U[q][1]), "+v"(U[q][2]), "+v"(U[q][3]), "+v"(U[q][4]), "+v"(U[q][5]), "+v"(U[q][6]), "+v"(U[q][7])
+                   : "n"((NR - 1) * 16) : "memory");
+      asm volatile("" : "+v"(X[q][0]), "+v"(X[q][1]), "+v"(X[q][2]), "+v"(X[q][3]), "+v"(X[q][4]), "+v"(X[q][5]), "+v"(X[q][6]), "+v"(X[q][7]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 2 * i + lrow;
+        *(u32x4*)(tb + r * 512 + ((lp ^ r) << 4)) = U[q][i];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 f = *(const u32x4*)(tb + r16 * 512 + (((4 * c + g) ^ r16) << 4));
+        acc = mfma16(f, X[q][c], acc);
+      }
+      ld_unit_x(SLOT, lt, ls); adv_unit();
+      if (++cs == UPT) {
+        cs = 0;
+        const int t = ct;
+        ct = next_tile(rem_cp);
+        finish_tile(t, acc);
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      return true;
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    while (unit(Q0{}) && unit(Q1{})) {}
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(U[0][0]), "v"(U[0][1]), "v"(U[0][2]), "v"(U[0][3]), "v"(U[0][4]), "v"(U[0][5]), "v"(U[0][6]), "v"(U[0][7]),
+                 "v"(U[1][0]), "v"(U[1][1]), "v"(U[1][2]), "v"(U[1][3]), "v"(U[1][4]), "v"(U[1][5]), "v"(U[1][6]), "v"(U[1][7]) : "memory");
+    asm volatile("" ::"v"(X[0][0]), "v"(X[0][1]), "v"(X[0][2]), "v"(X[0][3]), "v"(X[0][4]), "v"(X[0][5]), "v"(X[0][6]), "v"(X[0][7]),
+                 "v"(X[1][0]), "v"(X[1][1]), "v"(X[1][2]), "v"(X[1][3]), "v"(X[1][4]), "v"(X[1][5]), "v"(X[1][6]), "v"(X[1][7]) : "memory");
+  } else if constexpr (TRL) {
+    char* tb = smem + TB_OFF + wave * 8192;                 // this wave's transposition buffer: [16 rows][32 pieces of 16 B], piece ^ row
+    // one unit: wait for its 8 loads (the 24 younger ones stay in flight), rows -> LDS, refill the registers with the same unit of the
+    // tile after next, fragments <- LDS, 8 MFMAs.  LDS operations of one wave execute in order: no wait between the writes and the
+    // reads, nor between these reads and the next unit's writes.
+    // Unit n = (tile n / 2, half n % 2) sits in slot n % 3 and is refilled with unit n + 3 = (next tile, half 1) behind half 0,
+    // (tile after next, half 0) behind half 1.
+    auto unit = [&](auto SLOT, auto SUB, f32x4& acc, int tnext) __attribute__((always_inline)) {
+      constexpr int q = decltype(SLOT)::value, sub = decltype(SUB)::value;
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(U[q][0]), "+v"(U[q][1]), "+v"(U[q][2]), "+v"(U[q][3]), "+v"(U[q][4]), "+v"(U[q][5]), "+v"(U[q][6]), "+v"(U[q][7])
+                   : "n"((NR - 1) * 8) : "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 2 * i + lrow;
+        *(u32x4*)(tb + r * 512 + ((lp ^ r) << 4)) = U[q][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ld_nt_asm(U[q][i], unit_ptr(tnext, 1 - sub, i));
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 f = *(const u32x4*)(tb + r16 * 512 + (((4 * c + g) ^ r16) << 4));
+        acc = mfma16(f, xf[sub * 8 + c], acc);
+      }
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>; using Q2 = std::integral_constant<int, 2>;
+    // one tile at ring phase P (its halves sit in slots 2 P % 3 and (2 P + 1) % 3); false after the last tile
+    auto ttile = [&](auto S0, auto S1) __attribute__((always_inline)) -> bool {
+      if (ua < 0) return false;
+      (void)next_tile(rem_cp);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      unit(S0, Q0{}, acc, ub);
+      unit(S1, Q1{}, acc, uc);
+      finish_tile(ua, acc);
+      ua = ub; ub = uc; uc = next_tile(rem_ld);
+      return true;
+    };
+    while (ttile(Q0{}, Q1{}) && ttile(Q2{}, Q0{}) && ttile(Q1{}, Q2{})) {}
+    // drain: placeholder loads for tiles that do not exist may still be in flight into U; naming all 24 registers keeps the compiler
+    // from reusing any of them before the wait has executed
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(U[0][0]), "v"(U[0][1]), "v"(U[0][2]), "v"(U[0][3]), "v"(U[0][4]), "v"(U[0][5]), "v"(U[0][6]), "v"(U[0][7]),
+                 "v"(U[1][0]), "v"(U[1][1]), "v"(U[1][2]), "v"(U[1][3]), "v"(U[1][4]), "v"(U[1][5]), "v"(U[1][6]), "v"(U[1][7]),
+                 "v"(U[2][0]), "v"(U[2][1]), "v"(U[2][2]), "v"(U[2][3]), "v"(U[2][4]), "v"(U[2][5]), "v"(U[2][6]), "v"(U[2][7]) : "memory");
+  } else if constexpr (HOLD) {
     // one tile at ring phase P (its chunk c sits in slot (16 P + c) % 24); returns false after the last tile
     auto tile_phase = [&](auto P, auto STATIC) __attribute__((always_inline)) -> bool {
       constexpr int ph = decltype(P)::value;
@@ -366,7 +500,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
       // the straight-line form, with the (multiply, refill) pairs pinned in program order - although 23 younger loads are in flight:
       // the ring drains to a third every tile (measured: 3.0 TB/s against 5.9 for the batch-1 kernel).  The ring's first fill above is
       // hand-counted as well (a compiler-issued fill would be waited for with counts that ignore the asm loads: a full drain).
-      static_assert(MTG >= 12, "the straight-line part must fit one reduction group");
+      static_assert(MTG >= 12 || TRL, "the straight-line part must fit one reduction group");
       using T = std::true_type;
       do {
         if (!tile_phase(I0{}, T{})) break; if (!tile_phase(I1{}, T{})) break; if (!tile_phase(I2{}, T{})) break;
@@ -468,17 +602,23 @@ int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   d.grid = d.ntiles < 256 ? d.ntiles : 256;
   USDM_CHECK_ARG(cdiv(d.ntiles, d.grid) <= 64, "usdm_gemv_batch (matrix-core form): N too large (more than 64 tiles per workgroup)");
   USDM_CHECK_ARG(!lmh || pa->part_bs >= d.grid, "usdm_gemv_batch: part_bs must hold one partial per workgroup (%d)", d.grid);
-  void (*kfn)(const MfmaDev) = hold ? (d.cpw == 16 ? gemv_mfma_kernel<true, 16> : gemv_mfma_kernel<true, 0>)
-                                    : (d.cpw == 56 ? gemv_mfma_kernel<false, 56> : gemv_mfma_kernel<false, 0>);
+  // K = 4096 (every RMSNorm-fed projection and o_proj of the 7B): row-contiguous loads re-cut through LDS; form 3 forces the
+  // fragment-shaped loads there (A/B: tools/gemv_mfma_bench.py)
+  const bool trl = (hold ? d.cpw == 16 : d.cpw == 56) && pa->form != 3;
+  void (*kfn)(const MfmaDev) = trl ? (hold ? gemv_mfma_kernel<true, 16, true> : gemv_mfma_kernel<false, 56, true>)
+                             : hold ? (d.cpw == 16 ? gemv_mfma_kernel<true, 16, false> : gemv_mfma_kernel<true, 0, false>)
+                                    : (d.cpw == 56 ? gemv_mfma_kernel<false, 56, false> : gemv_mfma_kernel<false, 0, false>);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_TRL);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 56, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_TRL);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 56, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(d.grid), dim3(MW * 64), LDS_BYTES, st, d);
+  hipLaunchKernelGGL(kfn, dim3(d.grid), dim3(MW * 64), trl ? LDS_BYTES_TRL : LDS_BYTES, st, d);
   USDM_LAUNCH_CHECK();
   return 0;
 }
