@@ -69,7 +69,7 @@ class Pipeline:
                 probe, why = P2PComm.try_from_process_group(group, 3, 4096, timeout_ms=3000)
                 if probe is not None:
                     why = self_test(probe, group, dev, fused=fused)
-                    probe.close()
+                    probe.close(group)
                 if why is None:
                     comm, why = P2PComm.try_from_process_group(group, 2 * C7["num_hidden_layers"] + 1, C7["hidden_size"])
                 if why is not None:
@@ -91,7 +91,7 @@ class Pipeline:
                 self.llm.W = W
                 self.llm._alloc()
                 del old
-                comm.close()
+                comm.close(group)
                 self.tp_comm = f"rccl (p2p in-situ check failed: {why})"
         # Voicebox: the two classifier-free-guidance halves of every NFE on a PAIR of ranks (optional row): ranks
         # (2i, 2i+1) evaluate the unconditional / conditional estimator at batch 1 and all-gather the [1,80,S] velocities, instead

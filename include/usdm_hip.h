@@ -110,6 +110,8 @@ typedef struct usdm_gemm_args {
 } usdm_gemm_args;
 
 int usdm_gemm(const usdm_gemm_args* args, usdm_stream_t stream);
+int usdm_gemm_tile_for(const usdm_gemm_args* args); /* the tile usdm_gemm would pick (12..14 = ping-pong tiles: the only ones with the
+                                                        stats_out / ln_mode epilogues), < 0 for invalid arguments; launches nothing */
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm / RMSNorm over channels of [rows][C] activations (one wave per row).
@@ -179,7 +181,11 @@ typedef struct usdm_attn_args {
   const int32_t* kv_len;  /* [B] or NULL (= Skv) */
   const float* slopes;    /* [Hq] or NULL */
   int32_t window;         /* mode 1: > 0 = sliding window, query at position p sees keys p-window+1 .. p (HF Mistral sliding_window,
-                             src/model.py:337-371); 0 = full causal */
+                             src/model.py:337-371 keeps W - 1 past keys + the new one = the HF eager mask; the reference's flash-attn call
+                             passes window_size = (W, W), src/model.py:510,532, which admits W + 1 keys in a prefill: the two reference
+                             paths themselves differ by one key beyond 4096 tokens, and this follows the first); 0 = full causal */
+  int32_t variant;        /* mode 0, d = 64, speed only: 0 = 16-query waves (default), 1 = the 32-query-wave kernel (benchmarks; results agree
+                             to one bf16 ulp).  The library reads no environment variable per launch. */
 } usdm_attn_args;
 int usdm_attention(const usdm_attn_args* args, usdm_stream_t stream);
 

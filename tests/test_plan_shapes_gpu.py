@@ -73,8 +73,10 @@ def emulate(A, W, kw):
     ln = kw.get("ln")
     if ln:
         st = ln["stats"].double().cpu()
+        ncol = ln["C"] // ln["nt"]
         mean = st[..., 0].sum(-1) / ln["C"]
-        rstd = ((st[..., 1].sum(-1) / ln["C"] - mean * mean).clamp_min(0) + ln.get("eps", 1e-5)).rsqrt()
+        m2 = st[..., 1].sum(-1) + (ncol * (st[..., 0] / ncol - mean[..., None]) ** 2).sum(-1)      # pairwise merge of the tiles' M2
+        rstd = (m2 / ln["C"] + ln.get("eps", 1e-5)).rsqrt()
     out = {}          # (b, g) -> f64 [M, Nout]
     m = torch.arange(M)
     for b in range(Bt):
@@ -137,7 +139,8 @@ def check_call(dev, A, W, kw, name):
         ln = dict(ln)
         rows = ln["stats"].shape[0]
         x = torch.randn(rows, ln["nt"], ln["C"] // ln["nt"], generator=g) * 1.5 + 0.3
-        ln["stats"] = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).float().to(dev).contiguous()
+        # per-tile (sum, M2 about the tile's own mean): the producer's format since round 4
+        ln["stats"] = torch.stack([x.sum(-1), ((x - x.mean(-1, keepdim=True)) ** 2).sum(-1)], -1).float().to(dev).contiguous()
         kw["ln"] = ln
     outs = {k: kw[k] for k in ("out32", "out16") if kw.get(k) is not None}
     inputs = {x.untyped_storage().data_ptr() for x in (A, W, kw.get("residual")) if x is not None}

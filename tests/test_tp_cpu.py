@@ -200,3 +200,24 @@ def test_p2p_wiring_failures_keep_every_rank_in_the_collective_sequence():
         p.join(30)
     for rank, r1, r2, r3, tot in res:
         assert r1 == (True, True) and r2 == (True, True) and r3 and tot == 3.0, res
+
+
+def test_peer_only_error_word_raises():
+    """a rank whose own waits all succeeded but whose error word carries the PEER bit (another rank timed out and wrote
+    it through its mapping of this rank's buffer) must raise at its next host sync: the word is decoded on the host, no GPU needed."""
+    from usdm_amd.p2p import P2PComm, P2PError
+    assert P2PComm.describe_error(0, 3, 7) is None
+    own = P2PComm.describe_error(1, 3, 7)                       # USDM_P2P_ERR_TIMEOUT_ROWS on this rank
+    peer = P2PComm.describe_error(8 | 2, 3, 7)                  # a peer's TIMEOUT_PICK, marked PEER
+    assert "rank 3" in own and "this rank" in own and "PEER" not in own
+    assert "PEER" in peer and "0xa" in peer and "invalid" in peer
+
+    class Fake(P2PComm):
+        def __init__(self):
+            self.rank = 3
+        def status(self):
+            return 8 | 4, 11
+        def __del__(self):
+            pass
+    with pytest.raises(P2PError, match="PEER"):
+        Fake().raise_if_failed()

@@ -99,7 +99,7 @@ class AttnArgs(C.Structure):
         ("k", C.c_void_p), ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
         ("vt", C.c_void_p), ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_ds", C.c_int64),
         ("o", C.c_void_p), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
-        ("kv_len", C.c_void_p), ("slopes", C.c_void_p), ("window", C.c_int32),
+        ("kv_len", C.c_void_p), ("slopes", C.c_void_p), ("window", C.c_int32), ("variant", C.c_int32),
     ]
 
 

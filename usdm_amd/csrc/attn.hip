@@ -642,36 +642,23 @@ extern "C" int usdm_attention(const usdm_attn_args* pa, usdm_stream_t stream) {
   USDM_CHECK_ARG(a.Skv_alloc >= cdiv(a.Skv, KT) * KT, "usdm_attention: K/V^T buffers must be allocated (and finite) up to a multiple of %d keys", KT);
   USDM_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_ds % 8 == 0 && a.o_rs % 4 == 0, "usdm_attention: strides break 16-B alignment");
   USDM_CHECK_ARG(a.mode == 0 || a.mode == 1, "usdm_attention: mode");
+  USDM_CHECK_ARG(a.variant == 0 || a.variant == 1, "usdm_attention: variant");
   USDM_CHECK_ARG(a.window >= 0 && (a.window == 0 || a.mode == 1), "usdm_attention: window is a causal-mode (mode 1) option, >= 0");
   hipStream_t st = (hipStream_t)stream;
   usdm_attn_args a2 = a;
-  if (a2.mode == 0 && a2.head_order == 0) {      // default order of the bidirectional (Voicebox) form; USDM_ATTN_ORDER=0 restores flattest-first
-    static const int ord = getenv("USDM_ATTN_ORDER") ? atoi(getenv("USDM_ATTN_ORDER")) : 1;
-    a2.head_order = ord;
-  } else if (a2.head_order < 0) a2.head_order = 0;
-  // 2-wave workgroups (64 queries) when 4-wave ones would leave CUs with a single resident workgroup
-  const bool small = getenv("USDM_ATTN_NW2") && (int64_t)cdiv(a.Sq, 128) * a.Hq * a.B < 1024;
-  const int qb = small ? 64 : 128;
-  dim3 grid(cdiv(a.Sq, qb), a.Hq, a.B), block(small ? 128 : 256);
-  // key-split pairs of waves when the grid leaves about one 4-wave workgroup per CU and there are enough key tiles
-  static const int ks_env = getenv("USDM_ATTN_KS") ? atoi(getenv("USDM_ATTN_KS")) : -1;
-  const bool ks2 = !small && a.dh == 64 && a.mode == 0 && (ks_env == 2);   // measured: no gain in situ (NFE 5.65 vs 5.58 ms), kept as an experiment switch
-  if (ks2) {
-    hipLaunchKernelGGL((attn_kernel<64, 0, 4, 2>), grid, dim3(512), 0, st, a2);
-    USDM_LAUNCH_CHECK();
-    return 0;
-  }
-  // 16-query waves (8 per workgroup) for the Voicebox form: MHA, d = 64, bidirectional (USDM_ATTN_V16=0: the 32-query kernel)
-  const int v16 = getenv("USDM_ATTN_V16") ? atoi(getenv("USDM_ATTN_V16")) : 1;      // read per launch (tools/attn_bench.py flips it)
-  if (v16 && a.dh == 64 && a.mode == 0 && a.Hq == a.Hkv && !small) {
+  if (a2.mode == 0 && a2.head_order == 0) a2.head_order = 1;      // default order of the bidirectional (Voicebox) form; -1 = flattest first
+  else if (a2.head_order < 0) a2.head_order = 0;
+  const bool small = false;       // (2-wave workgroups and the key-split pairing measured no gain and are not instantiated: r02 / r03 notes)
+  dim3 grid(cdiv(a.Sq, 128), a.Hq, a.B), block(256);
+  // 16-query waves (8 per workgroup) for the Voicebox form: MHA, d = 64, bidirectional (usdm_attn_args.variant = 1: the 32-query kernel)
+  if (a.variant != 1 && a.dh == 64 && a.mode == 0 && a.Hq == a.Hkv) {
     hipLaunchKernelGGL((attn16_kernel<8>), grid, dim3(512), 0, st, a2);
     USDM_LAUNCH_CHECK();
     return 0;
   }
 #define USDM_ATTN(DHV, MODEV)                                                                 \
   do {                                                                                         \
-    if (small) hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 2>), grid, block, 0, st, a2);        \
-    else hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a2);              \
+    hipLaunchKernelGGL((attn_kernel<DHV, MODEV, 4>), grid, block, 0, st, a2);                   \
   } while (0)
   if (a.dh == 64 && a.mode == 0) USDM_ATTN(64, 0);
   else if (a.dh == 64) USDM_ATTN(64, 1);

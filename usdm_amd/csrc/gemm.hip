@@ -953,7 +953,8 @@ extern "C" int usdm_dbg_gemm_trace(unsigned long long* host, int n) {
 }
 #endif
 
-extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
+// validation + tile choice (+ launch unless tile_out: usdm_gemm_tile_for)
+static int gemm_impl(const usdm_gemm_args* pa, usdm_stream_t stream, int* tile_out) {
   USDM_CHECK_ARG(pa != nullptr, "usdm_gemm: null args");
   usdm_gemm_args a = *pa;
   if (a.groups <= 0) a.groups = 1;
@@ -1030,7 +1031,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
   if (a.tile_sel > 0) sel = (a.tile_sel & 0xff) - 1;   // benchmarking / test override (usdm_gemm_args.tile_sel; ops.gemm fills it from USDM_GEMM_TILE)
   if (a.taps != 1 && sel >= 4 && !(sel >= 12 && pp_taps)) sel = (sel == 6 || sel == 10) ? 1 : ((sel == 5 || sel == 7 || sel == 8) ? 2 : 0);   // DMA tiles are single-tap
   if (sel == 13 && (a.transpose_out || a.epi != USDM_EPI_PLAIN)) sel = 12;   // the 288-row tiles have row-major epilogues only
-  if (a.stats_out || a.ln_mode) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
+  if (!tile_out && (a.stats_out || a.ln_mode)) {      // folded LayerNorm: implemented in the epilogues of the ping-pong tiles only (see usdm_gemm_args)
     USDM_CHECK_ARG(sel >= 12 && sel <= 14 && a.dtype == USDM_BF16 && a.epi == USDM_EPI_PLAIN && !a.transpose_out && !a.round_bf16 &&
                        a.N % 128 == 0 && a.groups == 1 && (a.ldc & 3) == 0,
                    "usdm_gemm: stats_out / ln_mode need a bf16 GEMM on the ping-pong tiles with a row-major epilogue and N %% 128 == 0 (tile %d)", sel);
@@ -1044,6 +1045,7 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
                    "usdm_gemm: ln_mode 2 needs an f32 residual, gamma / beta and a plain epilogue");
     USDM_CHECK_ARG(a.ln_mode >= 0 && a.ln_mode <= 2, "usdm_gemm: ln_mode");
   }
+  if (tile_out) { *tile_out = sel; return 0; }
   if (a.dtype == USDM_BF16) {
     if (sel == 3) return launch<bf16_t, 128, 128, 2, 4>(a, st);
     if (sel == 4) return launch<bf16_t, 128, 128, 2, 2, true>(a, st);
@@ -1074,4 +1076,13 @@ extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) {
     if (sel == 1) return launch<float, 128, 64>(a, st);
     return launch<float, 64, 64>(a, st);
   }
+}
+
+extern "C" int usdm_gemm(const usdm_gemm_args* pa, usdm_stream_t stream) { return gemm_impl(pa, stream, nullptr); }
+// The tile usdm_gemm would run these arguments on (12 - 14: the ping-pong tiles, the only ones with the folded-LayerNorm epilogues),
+// or a negative number if the arguments are invalid: lets a caller decide BEFORE building a plan whether stats_out / ln_mode apply.
+extern "C" int usdm_gemm_tile_for(const usdm_gemm_args* pa) {
+  int tile = -1;
+  const int rc = gemm_impl(pa, nullptr, &tile);
+  return rc == 0 ? tile : -rc;
 }

@@ -989,9 +989,8 @@ extern "C" int usdm_gemv(const usdm_gemv_args* pa, usdm_stream_t stream) {
   }
   // (a 14-wave GLU variant with one workgroup per CU was measured 15 % slower than 7 four-wave workgroups per CU)
   // gate/up of the 7B (14336 outputs): 7-wave workgroups of 14 outputs = 1024 workgroups = exactly two rounds of two
-  // workgroups per CU, instead of 1792 four-wave workgroups = 1.75 rounds of four (USDM_GEMV_GLU7=0 restores that)
-  static const int glu7 = getenv("USDM_GEMV_GLU7") ? atoi(getenv("USDM_GEMV_GLU7")) : 1;
-  if (glu && glu7 && nout % 14 == 0 && (nout / 14) % 512 == 0) {
+  // workgroups per CU, instead of 1792 four-wave workgroups = 1.75 rounds of four
+  if (glu && nout % 14 == 0 && (nout / 14) % 512 == 0) {
     hipLaunchKernelGGL((gemv_kernel<2, true, 7>), dim3(nout / 14), dim3(448), lds, st, a);
     USDM_LAUNCH_CHECK();
     return 0;
@@ -1029,8 +1028,7 @@ extern "C" int usdm_gemv_threads(const usdm_gemv_args* pa) {
     if (nout / 256 == 16) return 1024;
     if (nout / 256 == 24) return 768;
   }
-  static const int glu7 = getenv("USDM_GEMV_GLU7") ? atoi(getenv("USDM_GEMV_GLU7")) : 1;
-  if (glu && glu7 && nout % 14 == 0 && (nout / 14) % 512 == 0) return 448;
+  if (glu && nout % 14 == 0 && (nout / 14) % 512 == 0) return 448;
   return 256;
 }
 

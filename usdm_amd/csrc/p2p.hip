@@ -27,12 +27,7 @@ extern "C" int usdm_allreduce_p2p_create(int32_t rank, int32_t world, int32_t n_
   c->rank = rank; c->world = world; c->n_sites = n_sites; c->max_elems = max_elems;
   c->bytes = usdm_allreduce_p2p_bytes(n_sites, max_elems);
   // Uncached device memory: peers write it over xGMI behind the back of this GPU's L2s, so no line of it may live in a cache.
-  // (USDM_P2P_ALLOC=finegrained|plain selects the other allocation kinds for experiments.)
-  const char* kind = getenv("USDM_P2P_ALLOC");
-  hipError_t e;
-  if (kind && !strcmp(kind, "plain")) e = hipMalloc(&c->local, c->bytes);
-  else if (kind && !strcmp(kind, "finegrained")) e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocFinegrained);
-  else e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocUncached);
+  hipError_t e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) { usdm_set_error("usdm_allreduce_p2p_create: allocation of %lld bytes -> %s", (long long)c->bytes, hipGetErrorString(e)); free(c); return 1; }
   if (hipMemset(c->local, 0, c->bytes) != hipSuccess || hipMalloc((void**)&c->dev_view, sizeof(usdm_p2p_dev)) != hipSuccess) {
     usdm_set_error("usdm_allreduce_p2p_create: memset / view allocation failed");

@@ -74,7 +74,7 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
          a_tap_stride=0, ldw=None, groups=1, batch=1, a_gstride=0, w_gstride=0, a_bstride=0, c_gcol=0,
          c_bstride=0, bias=None, alpha=1.0, act=0, round_bf16=False, residual=None, ldr=0,
          out32=None, out16=None, ldc=None, c_row_mul=1, c_row_off=0, transpose_out=False,
-         qkv=None, split_k=0, c_split_stride=0, stats_out=None, ln=None, plan=None):
+         qkv=None, split_k=0, c_split_stride=0, stats_out=None, ln=None, plan=None, tile_query=False):
     """Raw launch of usdm_gemm; see include/usdm_hip.h for the meaning of every field."""
     _need_cuda(A, W, bias, residual, out32, out16)
     a = GemmArgs()
@@ -110,6 +110,8 @@ def gemm(A, W, *, M, N, Kc, taps=1, lda=None, rowsA=None, a_row_mul=1, a_row_off
         a.epi = _lib.EPI_QKV_HEADS
         a.qkv_S, a.qkv_Spad, a.qkv_H, a.qkv_D = qkv["S"], qkv["Spad"], qkv["H"], qkv["D"]
         a.qkv_q, a.qkv_k, a.qkv_v = _ptr(qkv["q"]), _ptr(qkv["k"]), _ptr(qkv["v"])
+    if tile_query:
+        return lib.usdm_gemm_tile_for(C.byref(a))
     _go(plan, "usdm_gemm", lib.usdm_gemm, C.byref(a))
 
 
@@ -160,6 +162,9 @@ def attention(q, k, vt, o, *, mode, dh, B, Hq, Hkv, Sq, Skv, Skv_alloc, q_stride
     a.o, (a.o_bs, a.o_rs) = _ptr(o), o_strides
     a.kv_len, a.slopes = _ptr(kv_len), _ptr(slopes)
     a.window = int(window)
+    a.variant = 1 if os.environ.get("USDM_ATTN_V16", "1") == "0" else 0      # (tools/attn_bench.py: the 32-query-wave kernel)
+    if os.environ.get("USDM_ATTN_ORDER") == "0":
+        a.head_order = -1
     _go(plan, "usdm_attention", lib.usdm_attention, C_.byref(a))
 
 

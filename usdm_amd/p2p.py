@@ -121,14 +121,37 @@ class P2PComm:
         check(lib.usdm_allreduce_p2p_error(self._h, C.byref(err), C.byref(ep)), "usdm_allreduce_p2p_error")
         return err.value, ep.value
 
+    ERR_PEER = 8          # USDM_P2P_ERR_PEER (include/usdm_hip.h): ORed into THIS rank's word, with its own code, by a peer whose wait expired
+
+    @staticmethod
+    def describe_error(err, rank, epoch):
+        """Message for a non-zero error word; None for 0.  A word that carries only the PEER bit still raises: the rank that timed out
+        has substituted zeros for the missing partials, so every rank's results are invalid from that exchange on."""
+        if not err:
+            return None
+        codes, peer = err & ~P2PComm.ERR_PEER, bool(err & P2PComm.ERR_PEER)
+        what = "a PEER's wait expired (it carried on with zeros; its timeout code is included)" if peer else \
+               "a wait of this rank expired: a peer never delivered its partial sums within the bound"
+        return (f"peer-to-peer all-reduce failed on rank {rank} (error word {err:#x}: timeout codes {codes:#x}, epoch {epoch}): {what}; "
+                "results from this point on are invalid")
+
     def raise_if_failed(self):
         err, ep = self.status()
-        if err:
-            raise P2PError(f"peer-to-peer all-reduce timed out on rank {self.rank} (error word {err:#x}, epoch {ep}): a peer never "
-                           f"delivered its partial sums within the bound; results from this point on are invalid")
+        msg = self.describe_error(err, self.rank, ep)
+        if msg:
+            raise P2PError(msg)
 
-    def close(self):
+    def close(self, group=None):
+        """Unmaps the peers' buffers and frees this rank's.  Pass the process group to close COLLECTIVELY: a rank whose wait expires
+        writes the PEER bit into every peer's error word through its mapping of their buffers, so no rank may free its buffer while a
+        peer can still be inside a decode kernel - the barrier orders every rank's last launch before any unmap."""
         if self._h:
+            if group is not None:
+                import torch
+                import torch.distributed as dist
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                dist.barrier(group=group)
             lib.usdm_allreduce_p2p_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -273,6 +273,15 @@ class Transformer(nn.Module):
         # the separate LayerNorm kernel.  Needs the ping-pong tiles, i.e. the big shapes (R >= 1024 rows, 128-column multiples).
         ln_fold = (os.environ.get("USDM_VB_LN_FOLD", "1") == "1" and self.ln_fold_ok and use_split and nsp >= 2 and wo_split <= 1 and H % 128 == 0
                    and I % 128 == 0 and R >= 2048)
+        if ln_fold:
+            # the fold lives in the epilogues of the ping-pong tiles: ask the launcher which tile it would run the three GEMMs on
+            # (usdm_gemm_tile_for) instead of mirroring its heuristic here; any other tile -> the LayerNorm kernel
+            lp0 = P["layers"][0]
+            tiles = [ops.gemm(o16, lp0["wo"], M=R, N=H, Kc=H, bias=lp0["bo"], residual=h32, ldr=H, out32=tmp32, out16=pc16, tile_query=True),
+                     ops.gemm(pc16, lp0["w1g"], M=R, N=I, Kc=H, bias=lp0["d1"], act=ACT_GELU, out16=f16, tile_query=True),
+                     ops.gemm(f16, lp0["w2"], M=R, N=H, Kc=I, bias=lp0["b2"], residual=tmp32, ldr=H, out32=split2, split_k=nsp,
+                              c_split_stride=R * H, tile_query=True)]
+            ln_fold = all(12 <= t <= 14 for t in tiles)
         if ln_fold and self._ln_guard is None:
             self._ln_guard = torch.zeros(1, dtype=torch.int32, device=dev)
         nt1 = H // 128
