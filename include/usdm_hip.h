@@ -304,7 +304,8 @@ int usdm_gemv_threads(const usdm_gemv_args* args);   /* threads per workgroup us
  *                           step costs in HBM time for any nb <= 16.  Same rounding points (RMSNorm, bf16 outputs, SwiGLU,
  *                           residual, bf16 logits), but K is summed in a different order than usdm_gemv: equal to f32 rounding of
  *                           the accumulation, not bit for bit (csrc/llm_mfma_k.hip).
- * form: 0 = VALU for nb <= 4, matrix cores above; 1 = matrix cores; -1 = VALU (nb <= 4 only). */
+ * form: 0 = VALU for nb <= 4, matrix cores above; 1 = matrix cores; -1 = VALU (nb <= 4 only); 3 = matrix cores with
+ * fragment-shaped weight loads (A/B of the load pattern); 5 = matrix cores without the workgroup-level K split. */
 typedef struct usdm_gemv_batch_args {
   usdm_gemv_args g;          /* x_delta / x_out must be NULL */
   int32_t nb;
@@ -312,7 +313,14 @@ typedef struct usdm_gemv_batch_args {
   int32_t part_bs;            /* element stride between items of part_val / part_idx (>= usdm_gemv_nblocks; the matrix-core form
                                  writes one partial per workgroup (<= 256) and fills the rest with "no candidate") */
   int32_t form;
+  /* Matrix-core form, K split over workgroups (round 4; K > 4096 = down_proj): with ks_part / ks_cnt given and K %% 2048 == 0 (no
+   * RMSNorm, SwiGLU or lm_head mode) workgroup (s, j) multiplies K slice s (2048 wide, its activation slice HELD in registers) of its
+   * 16-row tiles; the K / 2048 partial tiles meet in ks_part (write-through stores), the workgroup that arrives last at a tile's
+   * counter sums them in slice order (deterministic) and runs the epilogue.  ks_part: usdm_gemv_batch_ks_floats(N, K) floats;
+   * ks_cnt: ceil(N / 16) int32, ZERO when the launch starts (every launch leaves them zero).  form 5 = do not split. */
+  float* ks_part; int32_t* ks_cnt; int64_t ks_part_floats;
 } usdm_gemv_batch_args;
+int64_t usdm_gemv_batch_ks_floats(int32_t N, int32_t K);   /* 0: this shape is not split */
 int usdm_gemv_batch(const usdm_gemv_batch_args* args, usdm_stream_t stream);
 
 /* Device-resident greedy-decode state so that a decode step is replayable as one hipGraph. */

@@ -140,6 +140,40 @@ def test_gemv_batch_matrix_core_form(dev, N, K, act, norm, res, nb):
     _close_bf16(Yb.cpu(), ref, "vs float64", ulps=3 if act == 3 else (2 if res else 1), mag=R.cpu() if res else None)
 
 
+@pytest.mark.parametrize("N,K,res", [(4096, 14336, True), (4096, 6144, False), (1000, 16384, True), (200, 14336, False)])
+@pytest.mark.parametrize("nb", [5, 16])
+def test_gemv_batch_k_split_over_workgroups(dev, N, K, res, nb):
+    """Matrix-core form with K split over workgroups (usdm_gemv_batch ks_part / ks_cnt; down_proj of the 7B: K = 14336 = 7 slices of
+    2048): partial tiles meet in device memory, the last arriver sums them in slice order.  Against float64 with the same rounding
+    points; three launches in a row on the same scratch (the counters must come back to zero, results must be REPRODUCIBLE bit for
+    bit whichever workgroup arrives last), in-place residual (y16 = residual) as the decode step uses it."""
+    from usdm_amd import ops
+    bf = torch.bfloat16
+    W = _r((N, K), 1, K ** -0.5).to(bf).to(dev)
+    X = _r((nb, K), 2).to(bf).to(dev)
+    R = _r((nb, N), 3).to(bf).to(dev) if res else None
+    ksf = ops.gemv_batch_ks_floats(N, K)
+    assert ksf == -(-N // 16) * (K // 2048) * 256
+    part = torch.full((ksf,), float("nan"), device=dev)
+    cnt = torch.zeros(-(-N // 16), dtype=torch.int32, device=dev)
+    outs = []
+    for rep in range(3):
+        Y = R.clone() if res else torch.full((nb, N), float("nan"), dtype=bf, device=dev)
+        ops.gemv_batch(W, X, nb=nb, N=N, K=K, x_bs=K, y_bs=N, res_bs=N, residual=Y if res else None, y16=Y, form=1, ks=(part, cnt))
+        assert int(cnt.abs().sum()) == 0, "tile counters not back at zero"
+        outs.append(Y.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the K-split sum depends on the arrival order"
+    assert bool(torch.isfinite(part).all())
+    ref = (X.double().cpu() @ W.double().cpu().T).to(bf)
+    if res:
+        ref = (ref.double() + R.double().cpu()).to(bf)
+    _close_bf16(outs[0].cpu(), ref, "K-split vs float64", ulps=2 if res else 1, mag=R.cpu() if res else None)
+    # and against the unsplit kernel (form 5): same rounding points, another summation order
+    Y5 = R.clone() if res else torch.zeros(nb, N, dtype=bf, device=dev)
+    ops.gemv_batch(W, X, nb=nb, N=N, K=K, x_bs=K, y_bs=N, res_bs=N, residual=Y5 if res else None, y16=Y5, form=5, ks=(part, cnt))
+    _close_bf16(outs[0], Y5, "K-split vs unsplit", ulps=2 if res else 1, mag=R if res else None)
+
+
 @pytest.mark.parametrize("nb", [3, 16])
 def test_gemv_batch_matrix_core_lm_head(dev, nb):
     """lm_head mode of the matrix-core form: bf16 logits, ban mask (whole banned tiles are not streamed), one arg-max partial per

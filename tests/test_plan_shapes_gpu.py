@@ -25,7 +25,8 @@ def capture_gemms(store):
     real = ops.gemm
 
     def spy(A, W, **kw):
-        store.append((A, W, dict(kw)))
+        if not kw.get("tile_query"):          # a tile query launches nothing
+            store.append((A, W, dict(kw)))
         return real(A, W, **kw)
     ops.gemm = spy
     try:

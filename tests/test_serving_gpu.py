@@ -66,7 +66,7 @@ def test_continuous_batching_vs_oracle(dev):
     from usdm_amd.llm import USDMForCausalLM
     from usdm_amd.serving import LLM, SamplingParams
     sd = MO.random_state_dict(SMALL, seed=43)
-    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256))
+    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256), max_num_seqs=4)
     g = torch.Generator().manual_seed(2)
 
     def ban(token_ids, logits):
@@ -105,7 +105,7 @@ def test_sampled_requests_inside_a_continuous_batch_equal_their_single_runs(dev)
     from usdm_amd.llm import USDMForCausalLM
     from usdm_amd.serving import LLM, SamplingParams
     sd = MO.random_state_dict(SMALL, seed=49)
-    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256))
+    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256), max_num_seqs=4)      # VALU form: bit-identical per slot
     g = torch.Generator().manual_seed(6)
 
     def ban(token_ids, logits):
@@ -174,7 +174,7 @@ def test_batched_request_running_into_the_context_limit(dev):
     from usdm_amd.serving import LLM, SamplingParams
     sd = MO.random_state_dict(SMALL, seed=47)
     m = USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=128)
-    eng = LLM(model=m)
+    eng = LLM(model=m, max_num_seqs=4)
     g = torch.Generator().manual_seed(5)
     lens = (101, 20, 99, 33, 25)                      # slots 0 and 2 hit the limit (27 / 29 tokens of room) at different steps
     want = (100000, 70, 100000, 60, 50)               # what the caller asks for (model_max_length-style for the long prompts)
@@ -238,3 +238,39 @@ def test_history_dependent_processor_and_sampling(dev):
     b = eng.generate(prompt_token_ids=[ids.tolist()], sampling_params=sp(1))[0].outputs[0].token_ids
     c = eng.generate(prompt_token_ids=[ids.tolist()], sampling_params=sp(2))[0].outputs[0].token_ids
     assert a == b and a != c and all(t >= 500 for t in a + c)
+
+
+def test_continuous_batching_16_slots_matrix_cores_vs_oracle(dev):
+    """Round 4: 22 greedy requests with one mask through the SIXTEEN decode slots of the matrix-core batch kernel (usdm_gemv_batch
+    form 1; the request lists of src/inference_vllm.py:109-125): ragged prompts, different max_tokens, a stop id, slot turnover
+    (22 requests on 16 slots); every sequence equals oracle greedy generation of its prompt under the near-tie rule."""
+    from oracle import mistral_oracle as MO
+    from tests._greedy_compare import check_against_oracle
+    from usdm_amd.llm import USDMForCausalLM
+    from usdm_amd.serving import LLM, MAX_SLOTS, SamplingParams
+    assert MAX_SLOTS == 16
+    sd = MO.random_state_dict(SMALL, seed=53)
+    eng = LLM(model=USDMForCausalLM.from_state_dict(sd, SMALL, dev, ctx_max=256))
+    g = torch.Generator().manual_seed(8)
+
+    def ban(token_ids, logits):
+        logits[0:250] = float("-inf")
+        return logits
+    bad = [[i] for i in range(250)]
+    n = 22
+    lens = [int(v) for v in torch.randint(12, 70, (n,), generator=g)]
+    prompts = [torch.randint(0, 1000, (L,), generator=g) for L in lens]
+    max_new = [int(v) for v in torch.randint(5, 36, (n,), generator=g)]
+    stop = MO.greedy_generate(sd, SMALL, prompts[1], 12, bad_words_ids=bad)[lens[1] + 5]
+    sps = [SamplingParams(max_tokens=mn, top_k=1, stop_token_ids=[stop], logits_processors=[ban]) for mn in max_new]
+    outs = eng.generate(prompt_token_ids=[p.tolist() for p in prompts], sampling_params=sps)
+    firsts = []
+    for p, mn, o in zip(prompts, max_new, outs):
+        ref, ref_logits = MO.greedy_generate(sd, SMALL, p, mn, bad_words_ids=bad, eos_token_id=stop, return_logits=True)
+        toks = o.outputs[0].token_ids
+        firsts.append(check_against_oracle(p.tolist() + toks, ref, ref_logits, p.numel()))
+        assert len(toks) <= mn and all(t >= 250 for t in toks)
+    st = eng.stats
+    print("16-slot continuous batching:", st, "first differences:", firsts)
+    assert st["batched_requests"] == n and st["admissions"] == n and st["max_active"] == 16
+    assert st["batched_steps"] < sum(max_new) // 4

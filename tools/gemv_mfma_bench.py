@@ -25,6 +25,8 @@ for name, N, K, act, norm, res, L in shapes:
     n = ops.gemv_nblocks(N)
     pv, pi = torch.zeros(nb, n, device=dev), torch.zeros(nb, n, dtype=torch.int32, device=dev)
     plan = ops.Plan()
+    ksf = ops.gemv_batch_ks_floats(N, K) if (nb > 4 or form in (1,)) and not lm else 0
+    ks = (torch.zeros(ksf, device=dev), torch.zeros(-(-N // 16), dtype=torch.int32, device=dev)) if ksf and form != 5 else None
     for W in Ws:
         if nb == 1 and form == 0:
             if lm:
@@ -34,7 +36,7 @@ for name, N, K, act, norm, res, L in shapes:
         elif lm:
             ops.gemv_batch(W, X, nb=nb, N=N, K=K, x_bs=K, part_bs=n, norm_w=g, part_val=pv, part_idx=pi, form=form, plan=plan)
         else:
-            ops.gemv_batch(W, X, nb=nb, N=N, K=K, x_bs=K, y_bs=nout, res_bs=nout, norm_w=g, act=act, residual=R, y16=Y, form=form, plan=plan)
+            ops.gemv_batch(W, X, nb=nb, N=N, K=K, x_bs=K, y_bs=nout, res_bs=nout, norm_w=g, act=act, residual=R, y16=Y, form=form, ks=ks, plan=plan)
     gp = GraphedPlan(plan)
     for _ in range(3):
         gp.run()

@@ -20,6 +20,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # (global: the experimental library resolves usdm_set_error here)
 lib.usdm_last_error.restype = C.c_char_p
+lib.usdm_gemv_batch_ks_floats.restype = C.c_int64
 _exp = None
 
 
@@ -144,7 +145,7 @@ class GemvChainArgs(C.Structure):
 class GemvBatchArgs(C.Structure):
     _fields_ = [
         ("g", GemvArgs), ("nb", C.c_int32), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("res_bs", C.c_int64), ("part_bs", C.c_int32),
-        ("form", C.c_int32),
+        ("form", C.c_int32), ("ks_part", C.c_void_p), ("ks_cnt", C.c_void_p), ("ks_part_floats", C.c_int64),
     ]
 
 

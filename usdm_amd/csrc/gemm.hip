@@ -73,6 +73,8 @@ __device__ unsigned long long g_gemm_trace[8192 * 8];
         if (ngate < a.N) {                                                                                                  \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) { bv[e] = bias[gcol + ngate + e]; bu[e] = bias[gcol + ngate + 16 + e]; } \
         }                                                                                                                   \
+      } else if (wide16) {                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { bv[e] = bias[gcol + n0 + ec8 + e]; bu[e] = bias[gcol + n0 + ec8 + 4 + e]; } \
       } else {                                                                                                              \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                       \
           if (n0 + ec + e < a.N) bv[e] = bias[gcol + n0 + ec + e];                                                          \
@@ -195,7 +197,18 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   const bool swiglu = a.act == USDM_ACT_SWIGLU;
   constexpr int C4 = BN / 4, RPI = NTH / C4, NIT = BM / RPI;
   const int ec = (tid % C4) * 4, er = tid / C4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};   // SwiGLU: gate / up
+  float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};   // SwiGLU: gate / up; 16-byte-store epilogue: columns 0-3 / 4-7
+  // 16-byte stores for the bf16 GELU epilogue of the ping-pong tiles (round 4): a thread owns 8 columns, so that a row of the tile
+  // is 16 lanes x 16 B instead of 32 x 8 B - the epilogue of a one-workgroup-per-CU tile is store-ISSUE-bound (3.5 - 5 us per
+  // workgroup, profiles/r04_gemm_ablation.txt) and half the store instructions is what shortens it (cdna_hip_programming.md T21)
+  constexpr int C8 = BN / 8, RPI8 = NTH / C8, NIT8 = BM / RPI8;
+  const int ec8 = (tid % C8) * 8, er8 = tid / C8;
+  const bool wide_gelu = PP && BM % RPI8 == 0 && a.act == USDM_ACT_GELU && !a.round_bf16 && !a.residual && a.C16 && !a.C32 && !a.transpose_out &&
+                         a.epi == USDM_EPI_PLAIN && n0 + BN <= a.N && (a.ldc & 7) == 0 && (gcol & 7) == 0 && (((uintptr_t)a.C16) & 15) == 0;
+  // ... and for the Q / K tiles of the head-split epilogue (8 consecutive features of one head per lane)
+  const bool wide_qk = PP && BM % RPI8 == 0 && a.epi == USDM_EPI_QKV_HEADS && n0 + BN <= 2 * a.qkv_H * a.qkv_D && (a.qkv_D & 7) == 0 &&
+                       ((((uintptr_t)a.qkv_q) | ((uintptr_t)a.qkv_k)) & 15) == 0;
+  const bool wide16 = wide_gelu || wide_qk;
   // outputs whose fast axis is m (transpose_out, V^T tiles of the head-split epilogue) go through a transposed LDS tile;
   // their per-column bias is staged in LDS (visible after the K loop's barriers)
   const bool tr_mode = a.transpose_out != 0 || (a.epi == USDM_EPI_QKV_HEADS && n0 >= 2 * a.qkv_H * a.qkv_D);
@@ -736,7 +749,31 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
     if (a.act == USDM_ACT_LOGCLAMP) return logf(fmaxf(x, 1e-5f));
     return x;
   };
-  if (is_qkv) {
+  if (is_qkv && wide_qk) {
+    const int HD = a.qkv_H * a.qkv_D;
+    const int n8 = n0 + ec8;
+    const int part = n8 / HD;                         // 0: Q, 1: K (V tiles took the transposed path)
+    const int hn = n8 - part * HD, qh = hn / a.qkv_D, qd = hn - qh * a.qkv_D;
+    bf16_t* base = (bf16_t*)(part == 0 ? a.qkv_q : a.qkv_k);
+    float4 ca = *(const float4*)(ct + er8 * CST + ec8), cb = *(const float4*)(ct + er8 * CST + ec8 + 4);
+    int b = (m0 + er8) / a.qkv_S, sq = (m0 + er8) - b * a.qkv_S;    // batch / position of the row, advanced incrementally
+#pragma unroll 2
+    for (int it = 0; it < NIT8; ++it) {
+      const int r = er8 + it * RPI8, m = m0 + r;
+      if (m >= a.M) break;
+      float v[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+      if (it + 1 < NIT8) { ca = *(const float4*)(ct + (r + RPI8) * CST + ec8); cb = *(const float4*)(ct + (r + RPI8) * CST + ec8 + 4); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = a.alpha * v[e] + (e < 4 ? bv[e] : bu[e - 4]);
+        if (rbf) v[e] = round_bf(v[e]);
+      }
+      uint4 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); p.z = pack_bf2(v[4], v[5]); p.w = pack_bf2(v[6], v[7]);
+      *(uint4*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;
+      sq += RPI8;
+      while (sq >= a.qkv_S) { sq -= a.qkv_S; ++b; }
+    }
+  } else if (is_qkv) {
     if (nv > 0) {
       const int HD = a.qkv_H * a.qkv_D;
       const int part = n / HD;                        // 0: Q, 1: K (V tiles took the transposed path)
@@ -760,6 +797,35 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         sq += RPI;
         while (sq >= a.qkv_S) { sq -= a.qkv_S; ++b; }
       }
+    }
+  } else if (wide_gelu) {
+    const int64_t rstep = (int64_t)RPI8 * a.c_row_mul;
+    int64_t row = ((int64_t)bz * a.c_bstride + m0 + er8) * a.c_row_mul + a.c_row_off;
+    const f32x2_t b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]}, b45 = {bu[0], bu[1]}, b67 = {bu[2], bu[3]};
+    f32x2_t lc01 = {0.f, 0.f}, lc23 = {0.f, 0.f}, lc45 = {0.f, 0.f}, lc67 = {0.f, 0.f};
+    if (a.ln_mode == 1) {
+      const float4 c0 = *(const float4*)(a.ln_c + gcol + n0 + ec8), c1 = *(const float4*)(a.ln_c + gcol + n0 + ec8 + 4);
+      lc01 = f32x2_t{c0.x, c0.y}; lc23 = f32x2_t{c0.z, c0.w}; lc45 = f32x2_t{c1.x, c1.y}; lc67 = f32x2_t{c1.z, c1.w};
+    }
+    float4 ca = *(const float4*)(ct + er8 * CST + ec8), cb = *(const float4*)(ct + er8 * CST + ec8 + 4);
+#pragma unroll 2
+    for (int it = 0; it < NIT8; ++it, row += rstep) {
+      const int r = er8 + it * RPI8;
+      if (m0 + r >= a.M) break;
+      const f32x2_t v01 = {ca.x, ca.y}, v23 = {ca.z, ca.w}, v45 = {cb.x, cb.y}, v67 = {cb.z, cb.w};
+      if (it + 1 < NIT8) { ca = *(const float4*)(ct + (r + RPI8) * CST + ec8); cb = *(const float4*)(ct + (r + RPI8) * CST + ec8 + 4); }
+      f32x2_t g01, g23, g45, g67;
+      if (a.ln_mode == 1) {          // folded LayerNorm: rstd * acc - rstd * mean * c[n] + bias'[n]
+        const float2 rs = *(const float2*)(rowst + 2 * r);
+        const f32x2_t r2 = {rs.x, rs.x}, nrm2 = {-rs.y, -rs.y};
+        g01 = gelu_erf2(fma2(v01, r2, fma2(lc01, nrm2, b01))); g23 = gelu_erf2(fma2(v23, r2, fma2(lc23, nrm2, b23)));
+        g45 = gelu_erf2(fma2(v45, r2, fma2(lc45, nrm2, b45))); g67 = gelu_erf2(fma2(v67, r2, fma2(lc67, nrm2, b67)));
+      } else {
+        g01 = gelu_erf2(v01 * a.alpha + b01); g23 = gelu_erf2(v23 * a.alpha + b23);
+        g45 = gelu_erf2(v45 * a.alpha + b45); g67 = gelu_erf2(v67 * a.alpha + b67);
+      }
+      uint4 p; p.x = pack_bf2v(g01); p.y = pack_bf2v(g23); p.z = pack_bf2v(g45); p.w = pack_bf2v(g67);
+      *(uint4*)((bf16_t*)a.C16 + row * a.ldc + gcol + n0 + ec8) = p;
     }
   } else if (PP && nv == 4 && vec_ok && a.act == USDM_ACT_GELU && !rbf && !resid && a.C16 && !C32p) {
     // the feed-forward GELU epilogue of the one-workgroup-per-CU tiles: nothing overlaps it there, so it is written for VALU

@@ -289,7 +289,7 @@ extern "C" int usdm_gemv_batch(const usdm_gemv_batch_args* pa, usdm_stream_t str
   USDM_CHECK_ARG(pa->g.N > 0 && pa->g.K > 0, "usdm_gemv_batch: bad N/K");
   USDM_CHECK_ARG(a.y16 || a.y32 || a.part_val, "usdm_gemv_batch: no output");
   USDM_CHECK_ARG(!a.x_delta && !a.x_out, "usdm_gemv_batch: x_delta / x_out are batch-1 (tensor-parallel) only");
-  if (pa->form == 1 || pa->form == 3 || (pa->form == 0 && pa->nb > 4)) return usdm_gemv_mfma_launch(pa, (hipStream_t)stream);
+  if (pa->form == 1 || pa->form == 3 || pa->form == 5 || (pa->form == 0 && pa->nb > 4)) return usdm_gemv_mfma_launch(pa, (hipStream_t)stream);
   USDM_CHECK_ARG(pa->nb >= 1 && pa->nb <= 4, "usdm_gemv_batch: the VALU form takes 1..4 sequences per step (form = 1 or nb > 4: matrix cores, <= 16)");
   USDM_CHECK_ARG(a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "usdm_gemv_batch: bad N/K/ldw");
   USDM_CHECK_ARG(a.K <= 16384, "usdm_gemv_batch: K too large for the LDS-resident input vectors");

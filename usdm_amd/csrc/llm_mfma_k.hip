@@ -43,7 +43,10 @@ constexpr int LDS_BYTES_TRL = TB_OFF + MW * 8192;
 struct MfmaDev {
   usdm_gemv_batch_args ba;
   int ntiles, rt, cpw, nchunks, grid, nout;
+  int ksplit, kwg;      // K split over workgroups: slices of ksplit_k elements, kwg workgroups per slice (1, grid: not split)
 };
+constexpr int KS_K = 2048;  // K per workgroup of the split form: 8 waves x 8 chunks, one 8-load unit per tile and wave
+constexpr int KS_MAX = 8;   // slices (K <= 16384)
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 w, u32x4 x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
@@ -93,12 +96,16 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   const bf16_t* Wb = (const bf16_t*)a.W;
 
   // ---- tiles of this workgroup: t = blockIdx.x + i * grid, i < ncand; lm_head: tiles whose 16 ids are all banned are not streamed
-  const int ncand = (d.ntiles - (int)blockIdx.x + d.grid - 1) / d.grid;
+  // (K split over workgroups: workgroup = (slice ksi, member tile0 of the kwg workgroups that share the slice))
+  const int ksi = d.ksplit > 1 ? (int)blockIdx.x % d.ksplit : 0;
+  const int tile0 = d.ksplit > 1 ? (int)blockIdx.x / d.ksplit : (int)blockIdx.x, tstep = d.kwg;
+  const int kofs = ksi * KS_K;
+  const int ncand = tile0 < d.ntiles ? (d.ntiles - tile0 + tstep - 1) / tstep : 0;
   unsigned long long mask = ncand >= 64 ? ~0ull : ((1ull << ncand) - 1ull);
   if (lmh && a.ban) {
     bool act = false;
     if (lane < ncand) {
-      const int t = blockIdx.x + lane * d.grid;
+      const int t = tile0 + lane * tstep;
       if (t * 16 + 16 <= a.N && (((uintptr_t)a.ban) & 15) == 0) {      // one 16-byte load per tile (sixteen dependent byte loads cost ~10 us)
         const u32x4 bv = *(const u32x4*)(a.ban + t * 16);
 #pragma unroll
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     if (a.y32) {      // the logits of tiles that are not streamed: -inf for every sequence (what the sampling kernel expects of banned ids)
       for (int i = 0; i < ncand; ++i) {
         if ((mask >> i) & 1ull) continue;
-        const int t = blockIdx.x + i * d.grid;
+        const int t = tile0 + i * tstep;
         for (int e = tid; e < 16 * nb; e += MW * 64) {
           const int n = t * 16 + (e & 15);
           if (n < a.N) a.y32[(int64_t)(e >> 4) * d.ba.y_bs + n] = -INFINITY;
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     if (!m) return -1;
     const int i = __builtin_ctzll(m);
     m &= m - 1;
-    return (int)blockIdx.x + i * d.grid;
+    return tile0 + i * tstep;
   };
   // Per-lane base of this wave's K slice of tile t (A-row r16), and of the activation slice.  Rows / sequences that do not exist are
   // CLAMPED to existing ones instead of masked: they only feed output rows / columns that the epilogue never stores, and every load
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   auto wload = [&](const u32x4* base, int c) -> u32x4 {
     return __builtin_nontemporal_load(base + c * 4);
   };
-  const u32x4* xbase = (const u32x4*)((const bf16_t*)a.x + (int64_t)min(r16, nb - 1) * d.ba.x_bs + (int64_t)kc0 * 32 + 8 * g);
+  const u32x4* xbase = (const u32x4*)((const bf16_t*)a.x + (int64_t)min(r16, nb - 1) * d.ba.x_bs + kofs + (int64_t)kc0 * 32 + 8 * g);
   auto xload = [&](int c) -> u32x4 { return xbase[c * 4]; };
 
   // ---- loads: the activation slice first (they return first: L2 hits), then the weights of the first two tiles
@@ -175,7 +182,8 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   u32x4 rx[HOLD ? 1 : CH];
   // ---- TRL: NR = 3 units of 8 row-contiguous loads (16 rows x 512 bytes = 8 chunks of this wave's K slice) = one and a half tiles in
   // flight (24 KiB per wave; four units next to the 16 held activation fragments spill)
-  constexpr int NR = HOLD ? 3 : 2;                          // (streamed activations: 16 loads per unit, two units = 32 KiB per wave)
+  // (streamed activations: 16 loads per unit, two units = 32 KiB per wave; the K-split form holds only 8 activation fragments: 4 units)
+  constexpr int NR = HOLD ? (CPWT == 8 ? 4 : 3) : 2;
   u32x4 U[TRL ? NR : 1][8];
   u32x4 X[(TRL && !HOLD) ? NR : 1][8];                     // streamed activations of the same units (K > 4096)
   const int lrow = lane >> 5, lp = lane & 31;              // row (of a pair) and 16-byte piece this lane loads
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     } else {
       row = min(t * d.rt + r, a.N - 1);
     }
-    return (const u32x4*)(Wb + (int64_t)row * a.ldw + (int64_t)wave * (cpw * 32) + sub * 256 + lp * 8);
+    return (const u32x4*)(Wb + (int64_t)row * a.ldw + kofs + (int64_t)wave * (cpw * 32) + sub * 256 + lp * 8);
   };
   int t0 = TRL ? -1 : next_tile(rem_ld), t1 = -1, t2 = -1;  // tile being multiplied, the next two (loads in flight / to be issued)
   const u32x4* wp0 = wbase(t0);
@@ -213,7 +221,16 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     ld_unit_x(std::integral_constant<int, 0>{}, lt, ls); adv_unit();
     ld_unit_x(std::integral_constant<int, 1>{}, lt, ls); adv_unit();
   }
-  if constexpr (TRL && HOLD) {
+  int tq[4] = {-1, -1, -1, -1};                             // K-split form: the tiles whose single unit sits in slots 0 .. 3
+  if constexpr (TRL && HOLD && CPWT == 8) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tq[q] = next_tile(rem_ld);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ld_nt_asm(U[q][i], unit_ptr(tq[q], 0, i));
+    }
+  }
+  if constexpr (TRL && HOLD && CPWT != 8) {
     ua = next_tile(rem_ld); ub = next_tile(rem_ld); uc = next_tile(rem_ld);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ld_nt_asm(U[0][i], unit_ptr(ua, 0, i));      // units 0, 1, 2 = (tile a, half 0), (a, 1), (b, 0)
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   // ---- epilogue of one fully reduced tile: lane (sequence b = r16, row group g) holds output rows 4 g .. 4 g + 3
   float bestv = -INFINITY;
   int besti = 0x7fffffff;
-  auto epilogue = [&](int t, f32x4 v) {
+  auto epilogue = [&](int t, f32x4 v) __attribute__((always_inline)) {
     const int b = r16;
     if (lmh) {
       float lv = -INFINITY;
@@ -355,18 +372,55 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   };
   // the tiles of a group are summed over the 16 waves in wave order (wave w < ng takes tile slot w) and finished
   int done = 0;
-  auto flush_group = [&](bool more) {
-    const int ng = ((done - 1) % MTG) + 1;
+  // K split over workgroups: this workgroup's partial tile goes to ks_part[t][slice] as write-through stores (the merging workgroup
+  // may sit on another XCD, whose L2 is not coherent with ours); once they are acknowledged, one relaxed increment of the tile's
+  // counter; the wave that arrives last reads all slices back (agent-scope loads, all in flight together) and sums them in SLICE
+  // order - the result does not depend on who was last.  No fences (an L2 write-back / invalidate per workgroup costs ~30 us).
+  auto ks_merge = [&](int t, f32x4& s) __attribute__((always_inline)) -> bool {
+    float* pp = d.ba.ks_part + (int64_t)t * d.ksplit * 256 + lane * 4;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp + ksi * 256), "v"(s) : "memory");
+    int old = 0;
+    if (lane == 0) {
+      old = __hip_atomic_fetch_add(d.ba.ks_cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == d.ksplit - 1) __hip_atomic_store(d.ba.ks_cnt + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != d.ksplit - 1) return false;
+    // all KS_MAX loads and their wait in ONE statement (slices that do not exist re-read the last one): nothing the compiler emits
+    // can sit between a load and its wait
+    f32x4 p[KS_MAX];
+    const float* q[KS_MAX];
+#pragma unroll
+    for (int k = 0; k < KS_MAX; ++k) q[k] = pp + min(k, d.ksplit - 1) * 256;
+    static_assert(KS_MAX == 8, "eight loads below");
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+        : "memory");
+    s = p[0];
+#pragma unroll
+    for (int k = 1; k < KS_MAX; ++k)
+      if (k < d.ksplit) s += p[k];
+    return true;
+  };
+  auto flush_group = [&](bool more) __attribute__((always_inline)) {
+    const int ng = ((done - 1) % MTG) + 1;                  // (the K-split form keeps all its <= MTG tiles for ONE flush after the stream)
     __syncthreads();
     for (int slot = wave; slot < ng; slot += MW) {
       f32x4 s = red[(slot * MW) * 64 + lane];
 #pragma unroll
       for (int w = 1; w < MW; ++w) s += red[(slot * MW + w) * 64 + lane];
+      if constexpr (TRL && HOLD && CPWT == 8) {
+        if (d.ksplit > 1 && !ks_merge(tl[slot], s)) continue;
+      }
       epilogue(tl[slot], s);
     }
     if (more) __syncthreads();
   };
-  auto finish_tile = [&](int t, f32x4 acc) {
+  auto finish_tile = [&](int t, f32x4 acc) __attribute__((always_inline)) {
     const int slot = done % MTG;
     red[(slot * MW + wave) * 64 + lane] = acc;
     if (tid == 0) tl[slot] = t;
@@ -413,6 +467,44 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
                  "v"(U[1][0]), "v"(U[1][1]), "v"(U[1][2]), "v"(U[1][3]), "v"(U[1][4]), "v"(U[1][5]), "v"(U[1][6]), "v"(U[1][7]) : "memory");
     asm volatile("" ::"v"(X[0][0]), "v"(X[0][1]), "v"(X[0][2]), "v"(X[0][3]), "v"(X[0][4]), "v"(X[0][5]), "v"(X[0][6]), "v"(X[0][7]),
                  "v"(X[1][0]), "v"(X[1][1]), "v"(X[1][2]), "v"(X[1][3]), "v"(X[1][4]), "v"(X[1][5]), "v"(X[1][6]), "v"(X[1][7]) : "memory");
+  } else if constexpr (TRL && CPWT == 8) {
+    // K split over workgroups: ONE unit per tile and wave (16 rows x 512 bytes of this wave's 256 K), four tiles in flight; tile n
+    // sits in slot n % 4 and is refilled with tile n + 4 as soon as its rows are in LDS
+    char* tb = smem + TB_OFF + wave * 8192;
+    // A round of four units is straight-line code: a unit whose tile does not exist (only behind the last tile: tiles are dealt to
+    // the slots in order) still waits, multiplies its placeholder lines and refills - only the hand-over of the result is conditional.
+    auto unit = [&](auto SLOT) __attribute__((always_inline)) {
+      constexpr int q = decltype(SLOT)::value;
+      const int t = tq[q];
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(U[q][0]), "+v"(U[q][1]), "+v"(U[q][2]), "+v"(U[q][3]), "+v"(U[q][4]), "+v"(U[q][5]), "+v"(U[q][6]), "+v"(U[q][7])
+                   : "n"((NR - 1) * 8) : "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 2 * i + lrow;
+        *(u32x4*)(tb + r * 512 + ((lp ^ r) << 4)) = U[q][i];
+      }
+      tq[q] = next_tile(rem_ld);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ld_nt_asm(U[q][i], unit_ptr(tq[q], 0, i));
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 f = *(const u32x4*)(tb + r16 * 512 + (((4 * c + g) ^ r16) << 4));
+        acc = mfma16(f, xf[c], acc);
+      }
+      if (t >= 0) {
+        red[(done * MW + wave) * 64 + lane] = acc;           // at most MTG tiles per workgroup (host): reduced and merged after the stream,
+        if (tid == 0) tl[done] = t;                          // when the load registers are free for the merge's partials
+        ++done;
+      }
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    while (tq[0] >= 0) { unit(Q0{}); unit(Q1{}); unit(Q2{}); unit(Q3{}); }
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(U[0][0]), "v"(U[0][1]), "v"(U[0][2]), "v"(U[0][3]), "v"(U[0][4]), "v"(U[0][5]), "v"(U[0][6]), "v"(U[0][7]),
+                 "v"(U[1][0]), "v"(U[1][1]), "v"(U[1][2]), "v"(U[1][3]), "v"(U[1][4]), "v"(U[1][5]), "v"(U[1][6]), "v"(U[1][7]),
+                 "v"(U[2][0]), "v"(U[2][1]), "v"(U[2][2]), "v"(U[2][3]), "v"(U[2][4]), "v"(U[2][5]), "v"(U[2][6]), "v"(U[2][7]) : "memory");
+    asm volatile("" ::"v"(U[3][0]), "v"(U[3][1]), "v"(U[3][2]), "v"(U[3][3]), "v"(U[3][4]), "v"(U[3][5]), "v"(U[3][6]), "v"(U[3][7]) : "memory");
   } else if constexpr (TRL) {
     char* tb = smem + TB_OFF + wave * 8192;                 // this wave's transposition buffer: [16 rows][32 pieces of 16 B], piece ^ row
     // one unit: wait for its 8 loads (the 24 younger ones stay in flight), rows -> LDS, refill the registers with the same unit of the
@@ -543,7 +635,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
         if (c < cpw) { ring[c] = wload(wp, c); rx[c] = xload(c); }
     }
   }
-  if (done % MTG) flush_group(false);
+  if (done % MTG || (TRL && HOLD && CPWT == 8 && done)) flush_group(false);
 
   // ---- lm_head: per-workgroup arg-max partial of every sequence (ties -> lowest id); unused partial slots keep "no candidate"
   if (lmh) {
@@ -569,6 +661,11 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
 }
 }  // namespace
 
+extern "C" int64_t usdm_gemv_batch_ks_floats(int32_t N, int32_t K) {
+  if (K <= MW * CH * 32 || K % KS_K != 0 || K / KS_K > KS_MAX || N <= 0) return 0;
+  return (int64_t)cdiv(N, 16) * (K / KS_K) * 256;
+}
+
 // called by usdm_gemv_batch (llm_batch_k.hip) for 5..16 sequences, or when the caller forces the matrix-core form
 int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   const usdm_gemv_args& a = pa->g;
@@ -585,6 +682,13 @@ int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
   USDM_CHECK_ARG(!lmh || (a.part_idx && !glu), "usdm_gemv_batch: lm_head partial buffers");
   d.nout = glu ? a.N / 2 : a.N;
   d.rt = 16;
+  d.ksplit = 1;
+  const int64_t ksf = usdm_gemv_batch_ks_floats(a.N, a.K);
+  if (ksf && pa->ks_part && pa->ks_cnt && !glu && !lmh && !a.norm_w && pa->form != 3 && pa->form != 5) {
+    USDM_CHECK_ARG(pa->ks_part_floats >= ksf && (((uintptr_t)pa->ks_part) & 15) == 0, "usdm_gemv_batch: ks_part must hold %lld floats (16-byte aligned)", (long long)ksf);
+    d.ksplit = a.K / KS_K;
+    if (cdiv(cdiv(a.N, 16), min(256 / d.ksplit, cdiv(a.N, 16))) > MTG_TRL) d.ksplit = 1;      // one reduction group per workgroup
+  }
   if (glu) {
     d.ntiles = cdiv(d.nout, 8);
   } else if (lmh) {
@@ -600,11 +704,26 @@ int usdm_gemv_mfma_launch(const usdm_gemv_batch_args* pa, hipStream_t st) {
     d.ntiles = cdiv(a.N, d.rt);
   }
   d.grid = d.ntiles < 256 ? d.ntiles : 256;
-  USDM_CHECK_ARG(cdiv(d.ntiles, d.grid) <= 64, "usdm_gemv_batch (matrix-core form): N too large (more than 64 tiles per workgroup)");
+  d.kwg = d.grid;
+  if (d.ksplit > 1) {      // 16-row tiles; 256 / ksplit workgroups per slice, each with every kwg-th tile
+    d.rt = 16;
+    d.ntiles = cdiv(a.N, 16);
+    d.kwg = min(256 / d.ksplit, d.ntiles);
+    d.grid = d.kwg * d.ksplit;
+    d.cpw = KS_K / 32 / MW;
+  }
+  USDM_CHECK_ARG(cdiv(d.ntiles, d.kwg) <= 64, "usdm_gemv_batch (matrix-core form): N too large (more than 64 tiles per workgroup)");
   USDM_CHECK_ARG(!lmh || pa->part_bs >= d.grid, "usdm_gemv_batch: part_bs must hold one partial per workgroup (%d)", d.grid);
   // K = 4096 (every RMSNorm-fed projection and o_proj of the 7B): row-contiguous loads re-cut through LDS; form 3 forces the
   // fragment-shaped loads there (A/B: tools/gemv_mfma_bench.py)
   const bool trl = (hold ? d.cpw == 16 : d.cpw == 56) && pa->form != 3;
+  if (d.ksplit > 1) {
+    static bool ks_attr = false;
+    if (!ks_attr) { (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_TRL); ks_attr = true; }
+    hipLaunchKernelGGL((gemv_mfma_kernel<true, 8, true>), dim3(d.grid), dim3(MW * 64), LDS_BYTES_TRL, st, d);
+    USDM_LAUNCH_CHECK();
+    return 0;
+  }
   void (*kfn)(const MfmaDev) = trl ? (hold ? gemv_mfma_kernel<true, 16, true> : gemv_mfma_kernel<false, 56, true>)
                              : hold ? (d.cpw == 16 ? gemv_mfma_kernel<true, 16, false> : gemv_mfma_kernel<true, 0, false>)
                                     : (d.cpw == 56 ? gemv_mfma_kernel<false, 56, false> : gemv_mfma_kernel<false, 0, false>);

@@ -622,6 +622,10 @@ class USDMForCausalLM:
             NS = max(-(-self.ctx_max // 512), min(self.NS, max(2, 512 // (B * Hkv))))
         pm, pl, po = Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS * d, dt=torch.float32)
         cache_bs = L * Hkv * self.ctx_max * d
+        # down_proj on the matrix cores (K = 14336): K split over workgroups, each holding its activation slice (usdm_gemv_batch ks_*);
+        # one scratch for all layers - the launches of a step are serial and each leaves the counters zero
+        ksf = ops.gemv_batch_ks_floats(H, I) if B > 4 else 0
+        ks = (Z(ksf, dt=torch.float32), Z(-(-H // 16), dt=torch.int32)) if ksf else None
         for l in range(L):
             w = self.W["layers"][l]
             ops.gemv_batch(w["qkv"], h, nb=B, N=nq, K=H, x_bs=H, y_bs=nq, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
@@ -630,7 +634,7 @@ class USDMForCausalLM:
             ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
             ops.gemv_batch(w["gu"], h, nb=B, N=2 * I, K=H, x_bs=H, y_bs=I, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU,
                            y16=act, plan=plan)
-            ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
+            ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, ks=ks, plan=plan)
         ops.gemv_batch(self.W["lm_head"], h, nb=B, N=self.v1 - self.v0, K=H, x_bs=H, part_bs=self.nparts, norm_w=self.W["norm"],
                        eps=c["rms_norm_eps"], ban=self.ban, part_val=bb["pv"], part_idx=bb["pi"], idx_offset=self.v0,
                        **(dict(y32=bb["logits"], y_bs=self.v1 - self.v0) if sampling else {}), plan=plan)

@@ -366,9 +366,10 @@ def rope_cache(qkv, cos, sin, kcache, vcache, *, ld, S, pos0, Hq, Hkv, ctx_max, 
 
 
 def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, norm_w=None, eps=1e-5, act=0, round_bf16=True,
-               residual=None, y16=None, y32=None, ban=None, part_val=None, part_idx=None, idx_offset=0, form=0, plan=None):
+               residual=None, y16=None, y32=None, ban=None, part_val=None, part_idx=None, idx_offset=0, form=0, ks=None, plan=None):
     """usdm_gemv_batch: the decode projection over nb <= 16 input vectors (x is [nb][x_bs], outputs [nb][y_bs]).
-    form 0: VALU kernel for nb <= 4, matrix-core kernel above; 1: matrix cores; -1: VALU."""
+    form 0: VALU kernel for nb <= 4, matrix-core kernel above; 1: matrix cores; -1: VALU; 3 / 5: A/B forms of the matrix-core kernel.
+    ks = (part f32 [gemv_batch_ks_floats(N, K)], counters int32 [ceil(N / 16)], zero): K split over workgroups (K > 4096)."""
     _need_cuda(W, x, norm_w, residual, y16, y32, ban, part_val, part_idx)
     b = GemvBatchArgs()
     a = b.g
@@ -378,7 +379,18 @@ def gemv_batch(W, x, *, nb, N, K, x_bs, y_bs=0, res_bs=0, part_bs=0, ldw=None, n
     a.residual, a.y16, a.y32 = _ptr(residual), _ptr(y16), _ptr(y32)
     a.ban, a.part_val, a.part_idx, a.idx_offset = _ptr(ban), _ptr(part_val), _ptr(part_idx), idx_offset
     b.nb, b.x_bs, b.y_bs, b.res_bs, b.part_bs, b.form = nb, x_bs, y_bs, res_bs, part_bs, form
+    if ks is not None:
+        part, cnt = ks
+        _need_cuda(part, cnt)
+        if part.dtype != torch.float32 or cnt.dtype != torch.int32 or cnt.numel() < -(-N // 16):
+            raise ValueError("usdm_gemv_batch: ks = (float32 partials, int32 counters [ceil(N / 16)])")
+        b.ks_part, b.ks_cnt, b.ks_part_floats = _ptr(part), _ptr(cnt), part.numel()
     _go(plan, "usdm_gemv_batch", lib.usdm_gemv_batch, C_.byref(b))
+
+
+def gemv_batch_ks_floats(N, K):
+    """floats of ks_part usdm_gemv_batch wants for this shape (0: the shape is not split over workgroups)"""
+    return int(lib.usdm_gemv_batch_ks_floats(C_.c_int32(N), C_.c_int32(K)))
 
 
 def attn_decode(qkv, pos, cos, sin, kcache, vcache, pm, pl, po, out, *, Hq, Hkv, ctx_max, NS, scale, counters=None, batch=0,

@@ -101,7 +101,10 @@ class LLM:
     download_dir), or `LLM(model=<USDMForCausalLM>, tokenizer=<tokenizer>)` around objects that are already loaded."""
 
     def __init__(self, model, tokenizer=None, download_dir=None, gpu_memory_utilization=0.9, max_model_len=None, device="cuda",
-                 dtype="bfloat16", **unused):
+                 dtype="bfloat16", max_num_seqs=MAX_SLOTS, **unused):
+        # max_num_seqs (vllm's name): sequences decoded per step, 1..16.  <= 4: the VALU batch kernel (per slot bit-identical with the
+        # single-request path); above: the matrix-core form (usdm_gemv_batch form 1)
+        self.max_slots = max(1, min(int(max_num_seqs), MAX_SLOTS))
         from .llm import USDMForCausalLM
         if isinstance(model, USDMForCausalLM):
             self.llm = model
@@ -228,7 +231,7 @@ class LLM:
     def _run_batched(self, grp):
         llm = self.llm
         from . import ops
-        nslots = SMALL_SLOTS if len(grp) <= SMALL_SLOTS else MAX_SLOTS
+        nslots = min(self.max_slots, SMALL_SLOTS if len(grp) <= SMALL_SLOTS else MAX_SLOTS)
         bb = llm._batch_buffers(nslots)
         sampled = any(not r["sp"].greedy for r in grp)       # one sampled request -> the whole group runs on the sampling graph
         key = "decode_sampled" if sampled else "decode"
