@@ -288,7 +288,9 @@ typedef struct usdm_gemv_args {
    * usdm_attn_decode(cmb_gran) clears them).  Every workgroup requests its first weight ring BEFORE it waits for the granules,
    * so the combine runs under the weight latency instead of in a launch of its own.  The wait is bounded (cmb_timeout_ms of the
    * 100 MHz clock); on expiry the workgroup ORs 1 into *cmb_err and carries on with zeros.  N = 16 * 256 outputs only (one
-   * 16-wave workgroup per CU, all co-resident). */
+   * 16-wave workgroup per CU, all co-resident): the hand-off ASSUMES that workgroups 0 .. K/128-1 are dispatched and make progress
+   * while the others poll, which holds exactly because the whole grid is resident at once; a launch for which it did not hold
+   * would cost one timeout per layer (and raise through *cmb_err), not hang. */
   unsigned long long* cmb_gran; int32_t* cmb_err; int32_t cmb_timeout_ms;
 } usdm_gemv_args;
 int usdm_gemv(const usdm_gemv_args* args, usdm_stream_t stream);

@@ -13,6 +13,11 @@ form = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 shapes = [("qkv   6144 x 4096 (norm)", 6144, 4096, 0, True, False, 24), ("o     4096 x 4096 (+res)", 4096, 4096, 0, False, True, 24),
           ("gu   28672 x 4096 (norm, swiglu)", 28672, 4096, 3, True, False, 24), ("down  4096 x 14336 (+res)", 4096, 14336, 0, False, True, 24),
           ("lm_head 42003 x 4096 (norm)", 42003, 4096, 0, True, False, 8)]
+if os.environ.get("EXTRA") == "1":      # what the small launches pay for: the RMSNorm prologue (same shape with / without), tiles per workgroup
+    shapes = [("qkv   6144 x 4096 (norm)", 6144, 4096, 0, True, False, 24), ("qkv   6144 x 4096 (no norm)", 6144, 4096, 0, False, False, 24),
+              ("o     4096 x 4096 (+res)", 4096, 4096, 0, False, True, 24), ("o     4096 x 4096 (norm)", 4096, 4096, 0, True, False, 24),
+              ("o2    8192 x 4096 (+res)", 8192, 4096, 0, False, True, 24), ("o4   16384 x 4096 (+res)", 16384, 4096, 0, False, True, 12),
+              ("half  2048 x 4096 (+res)", 2048, 4096, 0, False, True, 24)]
 tot = 0.0
 for name, N, K, act, norm, res, L in shapes:
     Ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(bf) for _ in range(L)]

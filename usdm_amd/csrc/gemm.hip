@@ -25,6 +25,9 @@
 #include <utility>
 #include <type_traits>
 
+#ifndef USDM_GEMM_WIDE16
+#define USDM_GEMM_WIDE16 1   // 0: the 8-byte-per-lane GELU / head-split epilogues of round 3 (A/B builds only)
+#endif
 namespace {
 
 struct GemmDev {
@@ -203,10 +206,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
   // workgroup, profiles/r04_gemm_ablation.txt) and half the store instructions is what shortens it (cdna_hip_programming.md T21)
   constexpr int C8 = BN / 8, RPI8 = NTH / C8, NIT8 = BM / RPI8;
   const int ec8 = (tid % C8) * 8, er8 = tid / C8;
-  const bool wide_gelu = PP && BM % RPI8 == 0 && a.act == USDM_ACT_GELU && !a.round_bf16 && !a.residual && a.C16 && !a.C32 && !a.transpose_out &&
+  const bool wide_gelu = USDM_GEMM_WIDE16 && PP && BM % RPI8 == 0 && a.act == USDM_ACT_GELU && !a.round_bf16 && !a.residual && a.C16 && !a.C32 && !a.transpose_out &&
                          a.epi == USDM_EPI_PLAIN && n0 + BN <= a.N && (a.ldc & 7) == 0 && (gcol & 7) == 0 && (((uintptr_t)a.C16) & 15) == 0;
   // ... and for the Q / K tiles of the head-split epilogue (8 consecutive features of one head per lane)
-  const bool wide_qk = PP && BM % RPI8 == 0 && a.epi == USDM_EPI_QKV_HEADS && n0 + BN <= 2 * a.qkv_H * a.qkv_D && (a.qkv_D & 7) == 0 &&
+  const bool wide_qk = USDM_GEMM_WIDE16 && PP && BM % RPI8 == 0 && a.epi == USDM_EPI_QKV_HEADS && n0 + BN <= 2 * a.qkv_H * a.qkv_D && (a.qkv_D & 7) == 0 &&
                        ((((uintptr_t)a.qkv_q) | ((uintptr_t)a.qkv_k)) & 15) == 0;
   const bool wide16 = wide_gelu || wide_qk;
   // outputs whose fast axis is m (transpose_out, V^T tiles of the head-split epilogue) go through a transposed LDS tile;

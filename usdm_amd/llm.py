@@ -619,8 +619,10 @@ class USDMForCausalLM:
             # many sequences: B x Hkv x NS workgroups of ctx / NS keys each.  The batch-1 choice (32 splits of ~20 keys: latency-bound,
             # one per CU) would be 4096 tiny workgroups at B = 16 (measured 35.6 us per layer); ~512 workgroups with up to 512 keys
             # (the split kernel's LDS bound) keep the KV stream at full width.  (B <= 4 keeps the batch-1 splits: bit-identical.)
-            NS = max(-(-self.ctx_max // 512), min(self.NS, max(2, 512 // (B * Hkv))))
+            NS = max(-(-self.ctx_max // 512), min(self.NS, max(2, getattr(self, "batch_attn_wgs", 512) // (B * Hkv))))
         pm, pl, po = Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS, dt=torch.float32), Z(B * Hq * NS * d, dt=torch.float32)
+        # (tools/batch_rate.py A/B: the merge by the last-arriving workgroup of a kv head instead of the combine launch)
+        cnt = Z(B * Hkv, dt=torch.int32) if B > 4 and getattr(self, "batch_fused_merge", False) else None
         cache_bs = L * Hkv * self.ctx_max * d
         # down_proj on the matrix cores (K = 14336): K split over workgroups, each holding its activation slice (usdm_gemv_batch ks_*);
         # one scratch for all layers - the launches of a step are serial and each leaves the counters zero
@@ -630,7 +632,8 @@ class USDMForCausalLM:
             w = self.W["layers"][l]
             ops.gemv_batch(w["qkv"], h, nb=B, N=nq, K=H, x_bs=H, y_bs=nq, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, bb["pos"], self.cos, self.sin, bb["kc"][0, l], bb["vc"][0, l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
-                            ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, window=self.window, plan=plan)
+                            ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, window=self.window,
+                            counters=cnt, plan=plan)
             ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
             ops.gemv_batch(w["gu"], h, nb=B, N=2 * I, K=H, x_bs=H, y_bs=I, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU,
                            y16=act, plan=plan)
