@@ -344,7 +344,12 @@ typedef struct usdm_decode_state {
  * do_sample=True, top_k=1 the reference samples among exact ties, of which this is one outcome). */
 int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
                       const usdm_decode_state* st, const void* embed_table_bf16, int32_t Hd, void* h_out_bf16,
-                      usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input);
+                      usdm_stream_t stream);
+/* The same pick over nseg SEGMENTS of nparts partials per sequence, seg_stride elements apart (sequence b's partials of segment s
+ * start at s * seg_stride + b * nparts): the tensor-parallel batched decode step all-gathers the ranks' [sequences][nparts] blocks
+ * into [rank][sequences][nparts] (SURVEY.md 8e + 8f-2). */
+int usdm_argmax_final_seg(const float* part_val, const int32_t* part_idx, int32_t nparts, int32_t nseg, int64_t seg_stride,
+                          const usdm_decode_state* st, const void* embed_table, int32_t Hd, void* h_out, usdm_stream_t stream);  /* embed_table != NULL: also h_out = table[token] (next step's input);
                                                  batched state: part_val/part_idx are [batch][nparts], h_out [batch][Hd] */
 
 /* Sampling twin of usdm_argmax_final: temperature -> top-k -> top-p (HF TemperatureLogitsWarper, TopKLogitsWarper,

@@ -404,8 +404,9 @@ static int gemv_pick_rw(int nout, bool glu) {
 }
 
 // final arg-max over the per-block partials; advances the device-side decode state
-__global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, usdm_decode_state st, const bf16_t* E, int Hd,
-                                    bf16_t* h_out) {
+// (nseg segments of nparts partials per sequence, seg_stride apart: the tensor-parallel batched step gathers [rank][sequence][nparts])
+__global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, int nseg, int64_t seg_stride, usdm_decode_state st,
+                                    const bf16_t* E, int Hd, bf16_t* h_out) {
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int s_tok;
@@ -414,11 +415,12 @@ __global__ void argmax_final_kernel(const float* pv, const int* pi, int nparts, 
   pv += (int64_t)b * nparts; pi += (int64_t)b * nparts;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < nparts; i += 256) {
-    const float v = pv[i];
-    const int id = pi[i];
-    if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
-  }
+  for (int sg = 0; sg < nseg; ++sg)
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+      const float v = pv[sg * seg_stride + i];
+      const int id = pi[sg * seg_stride + i];
+      if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+    }
   sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -1032,17 +1034,23 @@ extern "C" int usdm_gemv_threads(const usdm_gemv_args* pa) {
   return 256;
 }
 
+extern "C" int usdm_argmax_final_seg(const float* part_val, const int32_t* part_idx, int32_t nparts, int32_t nseg, int64_t seg_stride,
+                                     const usdm_decode_state* st, const void* embed_table, int32_t Hd, void* h_out,
+                                     usdm_stream_t stream) {
+  USDM_CHECK_ARG(part_val && part_idx && nparts > 0 && st && st->next_token && st->out_tokens && st->step && st->pos,
+                 "usdm_argmax_final: bad args");
+  USDM_CHECK_ARG(nseg >= 1 && (nseg == 1 || seg_stride >= (int64_t)nparts * (st->batch > 1 ? st->batch : 1)), "usdm_argmax_final_seg: segments overlap");
+  USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_argmax_final: embedding output missing");
+  USDM_CHECK_ARG(st->batch >= 0 && st->batch <= 64, "usdm_argmax_final: batch");
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(st->batch > 1 ? st->batch : 1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, nseg,
+                     seg_stride, *st, (const bf16_t*)embed_table, Hd, (bf16_t*)h_out);
+  USDM_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int usdm_argmax_final(const float* part_val, const int32_t* part_idx, int32_t nparts,
                                  const usdm_decode_state* st, const void* embed_table, int32_t Hd, void* h_out,
                                  usdm_stream_t stream) {
-  USDM_CHECK_ARG(part_val && part_idx && nparts > 0 && st && st->next_token && st->out_tokens && st->step && st->pos,
-                 "usdm_argmax_final: bad args");
-  USDM_CHECK_ARG(!embed_table || (h_out && Hd > 0 && Hd % 8 == 0), "usdm_argmax_final: embedding output missing");
-  USDM_CHECK_ARG(st->batch >= 0 && st->batch <= 64, "usdm_argmax_final: batch");
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(st->batch > 1 ? st->batch : 1), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts, *st,
-                     (const bf16_t*)embed_table, Hd, (bf16_t*)h_out);
-  USDM_LAUNCH_CHECK();
-  return 0;
+  return usdm_argmax_final_seg(part_val, part_idx, nparts, 1, 0, st, embed_table, Hd, h_out, stream);
 }
 
 extern "C" int usdm_embed_rows(const void* table, const int64_t* ids, const int32_t* next_token, int32_t n, int32_t Hd,

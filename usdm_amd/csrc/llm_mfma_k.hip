@@ -40,6 +40,14 @@ constexpr int LDS_BYTES = MTG_DEF * MW * 1024 + TAIL_BYTES;
 constexpr int TB_OFF = MTG_TRL * MW * 1024 + TAIL_BYTES;                                        // transposition buffers of the TRL variant
 constexpr int LDS_BYTES_TRL = TB_OFF + MW * 8192;
 
+#ifdef USDM_MFMA_TRACE
+// debugging aid (tools/gemv_mfma_trace.py): per-workgroup phase timestamps of wave 0 (100 MHz wall clock) + hardware ids
+__device__ unsigned long long g_mfma_trace[512 * 8];
+#define TRM(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_mfma_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TRM(i) do { } while (0)
+#endif
+
 struct MfmaDev {
   usdm_gemv_batch_args ba;
   int ntiles, rt, cpw, nchunks, grid, nout;
@@ -81,6 +89,11 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   constexpr int MTG = TRL ? MTG_TRL : MTG_DEF;             // tiles per reduction group
   constexpr int RED_BYTES = MTG * MW * 64 * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TRM(0);
+#ifdef USDM_MFMA_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 512)
+    g_mfma_trace[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+#endif
   f32x4* red = (f32x4*)smem;                               // [MTG][MW][64] partial D fragments
   float* gam = (float*)(smem + RED_BYTES);                 // [K <= 4096] RMSNorm weight
   float* ssum = gam + GAM_FLOATS;                          // [MW][16] partial sums of squares
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     wp2 = wbase(t2);
   }
 
+  TRM(1);
   // ---- RMSNorm of the held activation slice (HF: bf16(bf16(x * rstd) * weight)), under the weight loads
   if constexpr (HOLD) {
     if (a.norm_w) {
@@ -301,6 +315,10 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     }
   }
 
+#ifdef USDM_MFMA_TRACE
+  if constexpr (HOLD) asm volatile("s_nop 0" : "+v"(xf[0]), "+v"(xf[(CPWT > 0 ? CPWT : CH) - 1]));      // the held activations have landed / are normalised
+#endif
+  TRM(2);
   // ---- epilogue of one fully reduced tile: lane (sequence b = r16, row group g) holds output rows 4 g .. 4 g + 3
   float bestv = -INFINITY;
   int besti = 0x7fffffff;
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   auto flush_group = [&](bool more) __attribute__((always_inline)) {
     const int ng = ((done - 1) % MTG) + 1;                  // (the K-split form keeps all its <= MTG tiles for ONE flush after the stream)
     __syncthreads();
+    TRM(5);
     for (int slot = wave; slot < ng; slot += MW) {
       f32x4 s = red[(slot * MW) * 64 + lane];
 #pragma unroll
@@ -425,6 +444,9 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
     red[(slot * MW + wave) * 64 + lane] = acc;
     if (tid == 0) tl[slot] = t;
     ++done;
+#ifdef USDM_MFMA_TRACE
+    if (done == 1) TRM(3);
+#endif
     if (done % MTG == 0) flush_group(rem_cp != 0ull);
   };
 
@@ -496,6 +518,9 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
         red[(done * MW + wave) * 64 + lane] = acc;           // at most MTG tiles per workgroup (host): reduced and merged after the stream,
         if (tid == 0) tl[done] = t;                          // when the load registers are free for the merge's partials
         ++done;
+#ifdef USDM_MFMA_TRACE
+        if (done == 1) TRM(3);
+#endif
       }
     };
     using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
@@ -635,7 +660,12 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
         if (c < cpw) { ring[c] = wload(wp, c); rx[c] = xload(c); }
     }
   }
+  TRM(4);
   if (done % MTG || (TRL && HOLD && CPWT == 8 && done)) flush_group(false);
+#ifdef USDM_MFMA_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRM(6);
+#endif
 
   // ---- lm_head: per-workgroup arg-max partial of every sequence (ties -> lowest id); unused partial slots keep "no candidate"
   if (lmh) {
@@ -660,6 +690,12 @@ __global__ __launch_bounds__(MW * 64) void gemv_mfma_kernel(const MfmaDev d) {
   }
 }
 }  // namespace
+
+#ifdef USDM_MFMA_TRACE
+extern "C" int usdm_dbg_mfma_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mfma_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int64_t usdm_gemv_batch_ks_floats(int32_t N, int32_t K) {
   if (K <= MW * CH * 32 || K % KS_K != 0 || K / KS_K > KS_MAX || N <= 0) return 0;

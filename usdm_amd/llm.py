@@ -306,18 +306,22 @@ class USDMForCausalLM:
             return
         dist.all_reduce(t, group=self.group)
 
-    def _gather_partials(self):
+    def _gather_partials(self, dsts=None, srcs=None):
+        """all-gather of the ranks' arg-max partials (rank-major: dst = concatenation of the ranks' src along dim 0).  Default: the
+        single sequence's buffers; a batch slot / the batched step pass their own."""
         import torch.distributed as dist
+        dsts = [self.part_val, self.part_idx] if dsts is None else dsts
+        srcs = [self.part_val_loc, self.part_idx_loc] if srcs is None else srcs
         if hasattr(self.group, "usdm_all_gather"):
-            return self.group.usdm_all_gather(self.tp_rank, [self.part_val, self.part_idx], [self.part_val_loc, self.part_idx_loc])
+            return self.group.usdm_all_gather(self.tp_rank, dsts, srcs)
         if self._host_staged():
-            for dst, src in ((self.part_val, self.part_val_loc), (self.part_idx, self.part_idx_loc)):
+            for dst, src in zip(dsts, srcs):
                 c = torch.empty(dst.shape, dtype=dst.dtype)
                 dist.all_gather_into_tensor(c, src.cpu(), group=self.group)
                 dst.copy_(c)
             return
-        dist.all_gather_into_tensor(self.part_val, self.part_val_loc, group=self.group)
-        dist.all_gather_into_tensor(self.part_idx, self.part_idx_loc, group=self.group)
+        for dst, src in zip(dsts, srcs):
+            dist.all_gather_into_tensor(dst, src, group=self.group)
 
     def _lm_head_and_pick(self, plan, x, advance_pos, segs, sampling=None, x_delta=None, slot=None, skip=None):
         """lm_head GEMV + token choice.  sampling=None: ban-masked arg-max (the reference's top_k=1 path);
@@ -365,7 +369,8 @@ class USDMForCausalLM:
             return
         if self.tp_path:
             segs.append(plan)
-            segs.append(self._gather_partials)
+            segs.append(self._gather_partials if single else
+                        (lambda: self._gather_partials([sl.part_val, sl.part_idx], [sl.part_val_loc, sl.part_idx_loc])))
             plan = ops.Plan()
         # the picked token's embedding row is written straight into the decode step's input vector
         ops.argmax_final(sl.part_val, sl.part_idx, self.nparts * self.tp_size, st, embed=self.W["embed"], h_out=sl.h_dec,
@@ -588,6 +593,12 @@ class USDMForCausalLM:
                   pv=torch.zeros(B, self.nparts, dtype=torch.float32, device=dev), pi=i32(B, self.nparts), prefill=LRU(16), decode=None,
                   decode_sampled=None, logits=torch.zeros(B, self.v1 - self.v0, dtype=torch.float32, device=dev),
                   sp=ops.sample_params_tensor(dev, B).view(B, -1))
+        if self.tp_path:
+            # tensor parallel: pv / pi hold THIS rank's partials; the decode step gathers them rank-major into pvg / pig
+            # [rank][sequence][nparts] (usdm_argmax_final_seg), a slot's prefill into its own row of pvs / pis [sequence][rank * nparts]
+            tp = self.tp_size
+            bb.update(pvg=torch.zeros(tp, B, self.nparts, dtype=torch.float32, device=dev), pig=i32(tp, B, self.nparts),
+                      pvs=torch.zeros(B, tp * self.nparts, dtype=torch.float32, device=dev), pis=i32(B, tp * self.nparts))
         slots = []
         for b in range(B):
             sl = self._Slot()
@@ -596,6 +607,8 @@ class USDMForCausalLM:
             sl.h_dec = bb["h"][b]
             sl.part_val = sl.part_val_loc = bb["pv"][b]
             sl.part_idx = sl.part_idx_loc = bb["pi"][b]
+            if self.tp_path:
+                sl.part_val, sl.part_idx = bb["pvs"][b], bb["pis"][b]
             sl.logits, sl.sample_params = bb["logits"][b], bb["sp"][b]
             slots.append(sl)
         bb["slots"] = slots
@@ -628,25 +641,56 @@ class USDMForCausalLM:
         # one scratch for all layers - the launches of a step are serial and each leaves the counters zero
         ksf = ops.gemv_batch_ks_floats(H, I) if B > 4 else 0
         ks = (Z(ksf, dt=torch.float32), Z(-(-H // 16), dt=torch.int32)) if ksf else None
+        # Tensor parallel (SURVEY.md 8e x 8f-2; round 4, the collective form): the row-parallel projections leave f32 partial sums
+        # [B][H], all-reduced through the job's process group (RCCL: one collective of B x 16 KB per projection instead of B of them),
+        # then usdm_residual_add applies HF's rounding points; the plan is cut into segments at the collectives, as the
+        # single-sequence RCCL path is.  Greedy only (the sampling kernel needs the full logit row on one GPU).
+        tp = self.tp_path
+        if tp and sampling:
+            raise NotImplementedError("sampling needs the full logit row on one GPU (tensor-parallel decode is greedy only)")
+        segs = []
+        part, part2 = (Z(B, H, dt=torch.float32), Z(B, H, dt=torch.float32)) if tp else (None, None)
+
+        def row_parallel(W, x, K, buf, plan):
+            ops.gemv_batch(W, x, nb=B, N=H, K=K, x_bs=K, y_bs=H, round_bf16=False, y32=buf, plan=plan)
+            segs.extend([plan, (lambda t=buf: self._all_reduce(t))])
+            plan = ops.Plan()
+            ops.residual_add(h, buf, B * H, plan=plan)
+            return plan
         for l in range(L):
             w = self.W["layers"][l]
             ops.gemv_batch(w["qkv"], h, nb=B, N=nq, K=H, x_bs=H, y_bs=nq, norm_w=w["ln1"], eps=c["rms_norm_eps"], y16=qkv, plan=plan)
             ops.attn_decode(qkv, bb["pos"], self.cos, self.sin, bb["kc"][0, l], bb["vc"][0, l], pm, pl, po, ao, Hq=Hq, Hkv=Hkv,
                             ctx_max=self.ctx_max, NS=NS, scale=d ** -0.5, batch=B, qkv_bs=nq, out_bs=Hq * d, cache_bs=cache_bs, window=self.window,
                             counters=cnt, plan=plan)
-            ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
+            if tp:
+                plan = row_parallel(w["o"], ao, Hq * d, part, plan)
+            else:
+                ops.gemv_batch(w["o"], ao, nb=B, N=H, K=Hq * d, x_bs=Hq * d, y_bs=H, res_bs=H, residual=h, y16=h, plan=plan)
             ops.gemv_batch(w["gu"], h, nb=B, N=2 * I, K=H, x_bs=H, y_bs=I, norm_w=w["ln2"], eps=c["rms_norm_eps"], act=ACT_SWIGLU,
                            y16=act, plan=plan)
-            ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, ks=ks, plan=plan)
+            if tp:
+                plan = row_parallel(w["down"], act, I, part2, plan)
+            else:
+                ops.gemv_batch(w["down"], act, nb=B, N=H, K=I, x_bs=I, y_bs=H, res_bs=H, residual=h, y16=h, ks=ks, plan=plan)
         ops.gemv_batch(self.W["lm_head"], h, nb=B, N=self.v1 - self.v0, K=H, x_bs=H, part_bs=self.nparts, norm_w=self.W["norm"],
                        eps=c["rms_norm_eps"], ban=self.ban, part_val=bb["pv"], part_idx=bb["pi"], idx_offset=self.v0,
                        **(dict(y32=bb["logits"], y_bs=self.v1 - self.v0) if sampling else {}), plan=plan)
         st = ops.decode_state(bb["nxt"], bb["out"], bb["step"], bb["pos"], advance_pos=True, batch=B)
         if sampling:
             ops.sample_final(bb["logits"], st, dev_params=bb["sp"], embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
+        elif tp:      # vocab-parallel pick: the ranks' [B][nparts] partials gathered rank-major, one pick per sequence over all of them
+            segs.extend([plan, (lambda: self._gather_partials([bb["pvg"], bb["pig"]], [bb["pv"], bb["pi"]]))])
+            plan = ops.Plan()
+            ops.argmax_final(bb["pvg"], bb["pig"], self.nparts, st, embed=self.W["embed"], h_out=h, Hd=H, nseg=self.tp_size,
+                             seg_stride=B * self.nparts, plan=plan)
         else:
             ops.argmax_final(bb["pv"], bb["pi"], self.nparts, st, embed=self.W["embed"], h_out=h, Hd=H, plan=plan)
         plan.hold(st)
+        if tp:
+            segs.append(plan)
+            segs[0].hold(*[t for sg in segs if isinstance(sg, ops.Plan) for t in sg.keep])
+            return segs
         return plan
 
     MAX_BATCH = 16      # sequences per decode step (usdm_gemv_batch: VALU form up to 4, matrix-core form up to 16)
@@ -658,8 +702,6 @@ class USDMForCausalLM:
         step then streams the weights once for the whole group.  Groups of <= 4 run on the VALU kernel and equal generate() per
         sequence bit for bit; larger groups run on the matrix cores (usdm_gemv_batch form 1): the same rounding points, K summed
         in another order - equal to the oracle up to its near-ties, not bit-identical with generate()."""
-        if self.tp_path:
-            raise NotImplementedError("batched decode is single-GPU")
         group = self.MAX_BATCH if group is None else max(1, min(int(group), self.MAX_BATCH))
         outs = []
         for g0 in range(0, len(input_ids_list), group):
@@ -685,7 +727,8 @@ class USDMForCausalLM:
             io["ids"].copy_(ids[0])
             self._run_segs(segs)
         if bb["decode"] is None:
-            bb["decode"] = GraphedPlan(self._build_decode_batch(B))
+            built = self._build_decode_batch(B)
+            bb["decode"] = GraphedSegments(built, self._run_segs) if isinstance(built, list) else GraphedPlan(built)
         eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]) if eos_token_id is not None else set()
         produced, chunk = 1, 8
         ends = [None] * B

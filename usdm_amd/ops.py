@@ -321,8 +321,12 @@ def decode_state(next_token, out_tokens, step, pos, *, id_offset=0, advance_pos=
     return st
 
 
-def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, plan=None):
+def argmax_final(part_val, part_idx, nparts, st, embed=None, h_out=None, Hd=0, nseg=1, seg_stride=0, plan=None):
     _need_cuda(part_val, part_idx, embed, h_out)
+    if nseg > 1:      # [segment (rank)][sequence][nparts]: the gathered partials of a tensor-parallel batched step
+        _go(plan, "usdm_argmax_final_seg", lib.usdm_argmax_final_seg, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.c_int32(nseg),
+            C_.c_int64(seg_stride), C_.byref(st), _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
+        return
     _go(plan, "usdm_argmax_final", lib.usdm_argmax_final, _ptr(part_val), _ptr(part_idx), C_.c_int32(nparts), C_.byref(st),
         _ptr(embed), C_.c_int32(Hd), _ptr(h_out))
 

@@ -209,7 +209,7 @@ class InProcessGroup:
             for i in range(len(entries[0][0])):
                 cat = torch.cat([e[1][i] for e in entries])
                 for e in entries:
-                    e[0][i].copy_(cat)
+                    e[0][i].copy_(cat.reshape(e[0][i].shape))      # rank-major, as all_gather_into_tensor lays it out
             torch.cuda.synchronize()
         if self.threaded:
             self._slots[rank] = (dsts, srcs)

@@ -23,7 +23,7 @@ from collections import deque
 
 import torch
 
-from .graph import GraphedPlan
+from .graph import GraphedPlan, GraphedSegments
 
 MAX_SLOTS = 16      # usdm_gemv_batch streams the weights once per step for up to 16 sequences (matrix-core form above 4)
 SMALL_SLOTS = 4     # groups of <= 4 requests use the 4-slot plan (VALU form: per slot bit-identical with the single-request path)
@@ -180,7 +180,9 @@ class LLM:
         # continuous batching: requests with the same static mask (greedy and sampled alike), at least two of them
         groups = {}
         for r in reqs:
-            if r["mask"] is not None and r["max_new"] > 0 and not self.llm.tp_path:
+            # (tensor parallel: greedy requests only - the sampling kernel needs the full logit row on one GPU; every rank serves the
+            # same request list and sees the same tokens, so all ranks take the same scheduling decisions)
+            if r["mask"] is not None and r["max_new"] > 0 and (not self.llm.tp_path or r["sp"].greedy):
                 groups.setdefault(bytes(r["mask"].cpu().numpy().tobytes()), []).append(r)
         for grp in groups.values():
             if len(grp) >= 2:
@@ -236,7 +238,8 @@ class LLM:
         sampled = any(not r["sp"].greedy for r in grp)       # one sampled request -> the whole group runs on the sampling graph
         key = "decode_sampled" if sampled else "decode"
         if bb[key] is None:
-            bb[key] = GraphedPlan(llm._build_decode_batch(nslots, sampling=sampled))
+            built = llm._build_decode_batch(nslots, sampling=sampled)
+            bb[key] = GraphedSegments(built, llm._run_segs) if isinstance(built, list) else GraphedPlan(built)
         decode = bb[key]
         self.stats["sampled_in_batch"] = self.stats.get("sampled_in_batch", 0) + sum(not r["sp"].greedy for r in grp)
         for b in range(nslots):                               # idle slots: harmless greedy knobs
