@@ -131,3 +131,14 @@ __device__ __forceinline__ unsigned pack_bf2v(f32x2_t v) {          // one v_cvt
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Write-through (sc1) store of a kernel OUTPUT that the next launch consumes (see the note at st_out in gemm.hip: nothing dirty is
+// left in this XCD's L2 for the write-back at the kernel boundary).  The s_nop covers the store-data hazard of > 8-byte stores.
+template <class T>
+__device__ __forceinline__ void st_wt(T* p, const T& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int wt4;
+  typedef __attribute__((ext_vector_type(2))) unsigned int wt2;
+  if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(wt4, v)) : "memory");
+  else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(wt2, v)) : "memory");
+  else *p = v;
+}

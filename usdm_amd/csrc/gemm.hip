@@ -25,6 +25,25 @@
 #include <utility>
 #include <type_traits>
 
+// Epilogue outputs leave as WRITE-THROUGH stores (sc1; round 4).  A launch's output is consumed by the NEXT launch, mostly from other
+// XCDs (their L2s are not coherent with ours), so plain stores only park 13 - 27 MB of dirty lines in this XCD's L2 for the
+// write-back at the kernel boundary; written through while the epilogue runs, the boundary has nothing left to flush: Voicebox NFE
+// -3.3 % on two boxes (profiles/r04_gemm_ablation.txt E; `nt` stores instead: +7.5 %, the consumers then miss the last-level cache
+// as well).  A stronger scope bit is always a legal store.  The s_nop covers the store-data hazard hipcc handles for its own stores
+// (a VALU write to the data registers of a > 8-byte store in the next cycle): without it one ragged-tile test read garbage.
+#ifndef USDM_GEMM_WT_STORES
+#define USDM_GEMM_WT_STORES 1   // 0: plain stores (A/B builds)
+#endif
+template <class T>
+__device__ __forceinline__ void st_out(T* p, const T& v) {
+#if USDM_GEMM_WT_STORES
+  if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+  else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
+  else *p = v;
+#else
+  *p = v;
+#endif
+}
 #ifndef USDM_GEMM_WIDE16
 #define USDM_GEMM_WIDE16 1   // 0: the 8-byte-per-lane GELU / head-split epilogues of round 3 (A/B builds only)
 #endif
@@ -645,7 +664,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           bf16_t* vfeat = (bf16_t*)a.qkv_v + ((int64_t)h * a.qkv_D + d) * a.qkv_Spad;
           if (quad) {
             uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
-            *(uint2*)(vfeat + tok[0]) = p;
+            st_out((uint2*)(vfeat + tok[0]), p);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -735,8 +754,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         for (int e = 0; e < 4; ++e) o[e] = silu_mul(a.alpha * gt[e] + bv[e], a.alpha * up[e] + bu[e], rbf);
         const int64_t row = ((int64_t)bz * a.c_bstride + m) * a.c_row_mul + a.c_row_off;
         const int64_t oi = row * a.ldc + (gcol >> 1) + nout;
-        if (C32p) *(float4*)(C32p + oi) = make_float4(o[0], o[1], o[2], o[3]);
-        if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+        if (C32p) st_out((float4*)(C32p + oi), make_float4(o[0], o[1], o[2], o[3]));
+        if (a.C16) { uint2 p; p.x = pack_bf2(o[0], o[1]); p.y = pack_bf2(o[2], o[3]); st_out((uint2*)((bf16_t*)a.C16 + oi), p); }
       }
     }
     return;
@@ -772,7 +791,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         if (rbf) v[e] = round_bf(v[e]);
       }
       uint4 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); p.z = pack_bf2(v[4], v[5]); p.w = pack_bf2(v[6], v[7]);
-      *(uint4*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;
+      st_out((uint4*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd), p);
       sq += RPI8;
       while (sq >= a.qkv_S) { sq -= a.qkv_S; ++b; }
     }
@@ -796,7 +815,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           if (rbf) v[e] = round_bf(v[e]);
         }
         uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd) = p;   // D % 4 == 0, N % 4 == 0 (host-checked)
+        st_out((uint2*)(base + (((int64_t)b * a.qkv_H + qh) * a.qkv_Spad + sq) * a.qkv_D + qd), p);   // D % 4 == 0, N % 4 == 0 (host-checked)
         sq += RPI;
         while (sq >= a.qkv_S) { sq -= a.qkv_S; ++b; }
       }
@@ -828,7 +847,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         g45 = gelu_erf2(v45 * a.alpha + b45); g67 = gelu_erf2(v67 * a.alpha + b67);
       }
       uint4 p; p.x = pack_bf2v(g01); p.y = pack_bf2v(g23); p.z = pack_bf2v(g45); p.w = pack_bf2v(g67);
-      *(uint4*)((bf16_t*)a.C16 + row * a.ldc + gcol + n0 + ec8) = p;
+      st_out((uint4*)((bf16_t*)a.C16 + row * a.ldc + gcol + n0 + ec8), p);
     }
   } else if (PP && nv == 4 && vec_ok && a.act == USDM_ACT_GELU && !rbf && !resid && a.C16 && !C32p) {
     // the feed-forward GELU epilogue of the one-workgroup-per-CU tiles: nothing overlaps it there, so it is written for VALU
@@ -855,7 +874,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         g01 = gelu_erf2(v01 * a.alpha + b01); g23 = gelu_erf2(v23 * a.alpha + b23);
       }
       uint2 p; p.x = pack_bf2v(g01); p.y = pack_bf2v(g23);
-      *(uint2*)((bf16_t*)a.C16 + row * a.ldc + gcol + n) = p;
+      st_out((uint2*)((bf16_t*)a.C16 + row * a.ldc + gcol + n), p);
     }
   } else if (nv == 4 && vec_ok && a.act != USDM_ACT_NONE) {
     // activation epilogues: ROLLED loop so the transcendental code exists once (an unrolled epilogue grew the kernel to
@@ -891,8 +910,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
         }
       }
       const int64_t oi = row * a.ldc + gcol + n;
-      if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
-      if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+      if (C32p) st_out((float4*)(C32p + oi), make_float4(v[0], v[1], v[2], v[3]));
+      if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); st_out((uint2*)((bf16_t*)a.C16 + oi), p); }
     }
   } else if (nv == 4 && vec_ok) {
     // no activation: batches of NB rows, the residual rows of a batch all in flight before their first use (a load inside
@@ -966,8 +985,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const GemmDev g) {
           if ((tid & (C4 - 1)) == 0) *(float2*)(stp + (((row + u * rstep) * g.tiles_n + tn) << 1)) = make_float2(s1, s2);
         }
         const int64_t oi = (row + u * rstep) * a.ldc + gcol + n;
-        if (C32p) *(float4*)(C32p + oi) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); *(uint2*)((bf16_t*)a.C16 + oi) = p; }
+        if (C32p) st_out((float4*)(C32p + oi), make_float4(v[0], v[1], v[2], v[3]));
+        if (a.C16) { uint2 p; p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); st_out((uint2*)((bf16_t*)a.C16 + oi), p); }
       }
       row += NB * rstep;
     }

@@ -5,6 +5,15 @@
 #include "common.h"
 #include "../../include/usdm_hip.h"
 
+// outputs as write-through stores (see st_wt in common.h; NFE -0.8 %, profiles/r04_gemm_ablation.txt E)
+#ifndef USDM_NORM_WT
+#define USDM_NORM_WT 1   // 0: plain stores (A/B builds)
+#endif
+#if USDM_NORM_WT
+#define NST(p, v) st_wt(p, v)
+#else
+#define NST(p, v) (*(p) = (v))
+#endif
 namespace {
 constexpr int MAXP = 20;  // float4 pieces per lane: C <= 5120
 
@@ -62,10 +71,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
         x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
       }
       if (a.premask && zero_row) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.sum32) *(float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4) = x;
+      if (a.sum32) NST((float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4), x);
       if (a.sum16) {
         uint2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
-        *(uint2*)((bf16_t*)a.sum16 + (int64_t)row * a.lds + idx * 4) = o;
+        NST((uint2*)((bf16_t*)a.sum16 + (int64_t)row * a.lds + idx * 4), o);
       }
     }
     v[p] = x;
@@ -109,10 +118,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
       if (zero_row) t = 0.f;
       y[e] = t;
     }
-    if (a.out32) *(float4*)((float*)a.out32 + (int64_t)row * a.ldo + idx * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    if (a.out32) NST((float4*)((float*)a.out32 + (int64_t)row * a.ldo + idx * 4), make_float4(y[0], y[1], y[2], y[3]));
     if (a.out16) {
       uint2 o; o.x = pack_bf2(y[0], y[1]); o.y = pack_bf2(y[2], y[3]);
-      *(uint2*)((bf16_t*)a.out16 + (int64_t)row * a.ldo + idx * 4) = o;
+      NST((uint2*)((bf16_t*)a.out16 + (int64_t)row * a.ldo + idx * 4), o);
     }
   }
 }
