@@ -1,4 +1,6 @@
 """GPU parity of the universal tap-GEMM (usdm_gemm) against plain fp64 torch on the CPU."""
+import os
+
 import pytest
 import torch
 
@@ -319,6 +321,47 @@ def test_pingpong_tiles_bit_identical(dev, tile, tile_env):
 
         for x, y in zip(run(4, qkv), run(tile, qkv)):
             assert torch.equal(x, y), f"qkv S={S}: tile {tile} differs from tile 4"
+
+
+@pytest.mark.parametrize("M", [16, 38, 100])
+def test_short_prefill_tiles_bit_identical(dev, M, tile_env):
+    """Round 4: short 7B prefills (the 33 - 100 new rows behind a reused prefix) pick the 64x64 tile with four DMA stages (8) and the
+    128x128 ping-pong tile (14) instead of the 2-stage 64x64 tile (5).  The exact prefix reuse rests on a prefill row
+    not depending on how many rows were prefilled with it, i.e. on EVERY tile accumulating K in the same order: the LLM epilogues
+    (bf16-rounded residual add, SwiGLU pairs, plain bf16) must be bit-identical across the tiles a short and a long prefill use."""
+    from usdm_amd import ops
+    from usdm_amd._lib import ACT_SWIGLU
+    bf = torch.bfloat16
+    for (N, K) in [(768, 1088), (512, 2048), (1536, 1024)]:
+        A, W = _rand((M, K), bf, 51, 0.3).to(dev), _rand((N, K), bf, 52, 0.3).to(dev)
+        R = _rand((M, N), bf, 53).to(dev)
+
+        def residual():
+            o = torch.zeros((M, N), device=dev, dtype=bf)
+            ops.gemm(A, W, M=M, N=N, Kc=K, residual=R, ldr=N, round_bf16=True, out16=o)
+            return o
+
+        def swiglu():
+            o = torch.zeros((M, N // 2), device=dev, dtype=bf)
+            ops.gemm(A, W, M=M, N=N, Kc=K, act=ACT_SWIGLU, round_bf16=True, out16=o, ldc=N // 2)
+            return o
+
+        def plain():
+            o = torch.zeros((M, N), device=dev, dtype=bf)
+            ops.gemm(A, W, M=M, N=N, Kc=K, out16=o)
+            return o
+        for name, f in (("residual", residual), ("swiglu", swiglu), ("plain", plain)):
+            tile_env(4)
+            ref = f()
+            for t in (5, 8, 10, 14, 12):
+                tile_env(t)
+                assert torch.equal(ref, f()), f"{name} {M}x{N}x{K}: tile {t} differs from tile 4"
+    os.environ.pop("USDM_GEMM_TILE", None)
+    # and the automatic choice for the 7B's short-prefill shapes
+    for (N, K, want) in [(6144, 4096, 8), (4096, 14336, 8), (28672, 4096, 14)]:
+        A, W = torch.zeros(M, K, device=dev, dtype=bf), torch.zeros(8, K, device=dev, dtype=bf)      # (the query reads no memory)
+        o = torch.zeros(M, 8, device=dev, dtype=bf)
+        assert ops.gemm(A, W, M=M, N=N, Kc=K, out16=o, ldc=N, tile_query=True) == want
 
 
 def test_pingpong_selected_for_big_linear(dev):

@@ -1091,11 +1091,14 @@ static int gemm_impl(const usdm_gemm_args* pa, usdm_stream_t stream, int* tile_o
   const int64_t t12 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 128) * z, t13 = (int64_t)cdiv(a.M, 288) * cdiv(a.N, 128) * z;
   const bool pp_taps = a.taps == 1 || (a.a_row_step == 0 && a.Kc % 64 == 0);      // single tap, or sources concatenated along K
   const bool pp_ok = heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 && t12 >= 96 && a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256 &&
-                     (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
+                     (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;      // (= rows256_ok below)
   // ... and its 128x128 form where the big tiles would leave half the CUs idle (96-256 tiles of 128x128, one per CU)
   const int64_t t14 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * z;
+  // (also where 256-row tiles would be mostly padding: the 33 - 100 row prefills of a reused prefix stream gate/up's 235 MB through
+  // 224 such tiles at 4.1 TB/s, 57 us against 67 - 90 on the 128x64 tile; profiles/r04_prefill_small.log)
+  const bool rows256_ok = (int64_t)cdiv(a.M, 256) * 256 * 2 <= (int64_t)a.M * 3;
   const bool pp_small = heur == 1 && a.dtype == USDM_BF16 && pp_taps && a.N > 64 &&   // (K-concatenated sources included: the skip Linear 31.1 -> 25.7 us, r03_vb_ablation.txt 8)
-                        t12 < 128 && t14 >= 96 && t14 <= 256 &&
+                        (t12 < 128 || !rows256_ok) && t14 >= 96 && t14 <= 256 &&
                         a.Kc / (a.split_k > 1 ? a.split_k : 1) >= 256;
   if (pp_small) sel = 14;
   else if (pp_ok) {
@@ -1110,7 +1113,9 @@ static int gemm_impl(const usdm_gemm_args* pa, usdm_stream_t stream, int* tile_o
     else if (a.Kc >= 2048 && t12864 >= 256) sel = 10;                  // deep K, few tiles: 128x64, 3 stages
     else if (t128 >= 400 && t128 <= 512) sel = 4;                      // exactly one round of 2 workgroups per CU
     else if (a.N >= 2048 && t12864 >= 768) sel = 6;
-    else sel = 5;
+    // few tiles: weight streaming through a handful of CUs is latency-bound - the 64x64 tile with FOUR DMA stages in flight (short
+    // 7B prefills: qkv / o 52 -> 27 us, down 169 -> 84 us; f32 shapes measure the same on 2 and 4 stages and keep the 2-stage tile)
+    else sel = (a.dtype == USDM_BF16 && a.Kc >= 1024) ? 8 : 5;
   }
   // multi-tap operands (convolutions): register-staged loaders (the DMA path recomputes the tap row shift per K-step)
   else if (t128 >= 640) sel = (a.taps == 1) ? 4 : 0;
