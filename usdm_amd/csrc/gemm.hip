@@ -1105,7 +1105,7 @@ static int gemm_impl(const usdm_gemm_args* pa, usdm_stream_t stream, int* tile_o
     const int64_t c12 = cdiv(t12, 256) * 256, c13 = cdiv(t13, 256) * 288;     // rounds x rows per tile
     sel = (!a.transpose_out && a.epi == USDM_EPI_PLAIN && c13 < c12) ? 13 : 12;
   }
-  else if (a.N <= 64) sel = (cdiv(a.M, 128) * z >= 448) ? 1 : 2;
+  else if (a.N <= 64) sel = (a.dtype != USDM_F32 && cdiv(a.M, 128) * z >= 448) ? 1 : 2;   // (f32: the 64x64 tile is 7 - 17 % faster on BigVGAN's 24 / 48-channel stages, profiles/r04_bigvgan_conv_tiles.log)
   else if (heur == 1 && a.taps == 1) {
     if (a.split_k > 1 && t128 >= 224 && t128 <= 512) sel = 4;          // split-K partials filling one round of the big tile
     else if (t128 >= 640) sel = 4;                                     // many rounds of the big tile

@@ -507,7 +507,10 @@ __global__ void rope_cache_kernel(const usdm_rope_args a) {
 // its kv head) and the new k itself, so no block depends on another block's cache write.
 // ---------------------------------------------------------------------------------------------
 constexpr int DA_KMAX = 512;  // max keys per split
-template <int G>
+// PIPE (round 4, the many-sequence step: few splits of up to 512 keys each): the K / V rows of the NEXT batch of keys are requested
+// before the current batch is consumed (second register set).  The batch-1 step (NS = 32: ~20 keys per split, one batch) keeps
+// the plain form.  Same keys per thread in the same order: bit-identical results (profiles/r04_decode_ablation.txt 11).
+template <int G, bool PIPE = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode_args a) {
   __shared__ float qs[G][128];
   __shared__ float knew[128], vnew[128];
@@ -585,8 +588,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 16; ++e) qr[h][e] = qs[h][j * 16 + e];
+    u32x4 n0[PIPE ? SW : 1], n1[PIPE ? SW : 1];      // PIPE: the next batch's rows
     for (int base = 0; base < nk; base += 32 * SW) {
-      if (base > 0) {
+      if constexpr (PIPE) {
+        // unconditional (clamped) requests: a branch here would make the wait-count pass drain everything at the join
+#pragma unroll
+        for (int w = 0; w < SW; ++w) {
+          const int kk = min(base + 32 * SW + 32 * w + gk, nk - 1);
+          const bf16_t* kp = Kc + (int64_t)(k0 + kk) * 128 + j * 16;
+          n0[w] = *(const u32x4*)kp;
+          n1[w] = *(const u32x4*)(kp + 8);
+        }
+      } else if (base > 0) {
 #pragma unroll
         for (int w = 0; w < SW; ++w) {
           const int kk = min(base + 32 * w + gk, nk - 1);
@@ -619,6 +632,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
           if (j == 0) sc[h][kk] = sdot * a.scale;
         }
       }
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int w = 0; w < SW; ++w) { r0[w] = n0[w]; r1[w] = n1[w]; }
+      }
     }
   }
   __syncthreads();
@@ -644,8 +661,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
     for (int h = 0; h < G; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
+    u32x2 nv[PIPE ? PW : 1];
     for (int base = 0; base < nk; base += 8 * PW) {
-      if (base > 0) {
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int w = 0; w < PW; ++w) {
+          const int kk = min(base + 8 * PW + 8 * w + kl, nk - 1);
+          nv[w] = *(const u32x2*)(Vc + (int64_t)(k0 + kk) * 128 + d4);
+        }
+      } else if (base > 0) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
           const int kk = min(base + 8 * w + kl, nk - 1);
@@ -667,6 +691,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const usdm_attn_decode
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
         }
+      }
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int w = 0; w < PW; ++w) rv[w] = nv[w];
       }
     }
 #pragma unroll
@@ -1105,7 +1133,11 @@ extern "C" int usdm_attn_decode(const usdm_attn_decode_args* pa, usdm_stream_t s
   }
   const int nbatch = a.batch > 1 ? a.batch : 1;
   dim3 grid(a.Hkv, a.NS, nbatch);
-  if (G == 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, st, a);
+  const bool pipe = nbatch > 1 && cdiv(span, a.NS) > 64;      // long splits (the many-sequence step): next batch of keys prefetched
+  if (pipe && G == 4) hipLaunchKernelGGL((attn_decode_kernel<4, true>), grid, dim3(256), 0, st, a);
+  else if (pipe && G == 2) hipLaunchKernelGGL((attn_decode_kernel<2, true>), grid, dim3(256), 0, st, a);
+  else if (pipe && G == 1) hipLaunchKernelGGL((attn_decode_kernel<1, true>), grid, dim3(256), 0, st, a);
+  else if (G == 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, st, a);
   else if (G == 2) hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), 0, st, a);
   else if (G == 1) hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, st, a);
   else { usdm_set_error("usdm_attn_decode: group size %d unsupported (1,2,4)", G); return 2; }
