@@ -64,6 +64,23 @@ def test_generate_batch_equals_generate(dev):
     assert singles[1].shape[1] <= 17 + 10
 
 
+def test_generate_batch_falls_back_to_four_when_k_does_not_fit_the_matrix_core_form(dev):
+    """The matrix-core form splits K over 8 waves in chunks of 32: a model whose projections have a K that is not a multiple of 256
+    (hidden 384 here) must not fail on a list of more than 4 prompts - max_batch() says 4 and the list runs in groups of 4 on the
+    VALU kernel, every sequence bit-identical with generate()."""
+    from usdm_amd.llm import USDMForCausalLM
+    cfg = dict(vocab_size=1000, hidden_size=384, intermediate_size=640, num_hidden_layers=2, num_attention_heads=3,
+               num_key_value_heads=3, head_dim=128, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=32768)
+    m = USDMForCausalLM.random_init(cfg, dev, seed=9, ctx_max=128)
+    assert m.max_batch() == 4
+    gen = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, 1000, (1, L), generator=gen).to(dev) for L in (21, 9, 33, 17, 26, 12)]
+    singles = [m.generate(input_ids=p, max_new_tokens=12) for p in prompts]
+    batch = m.generate_batch(prompts, max_new_tokens=12)
+    for s_, b_ in zip(singles, batch):
+        assert torch.equal(s_, b_)
+
+
 @pytest.mark.parametrize("group", [4, 16])
 def test_generate_batch_vs_oracle(dev, group):
     """Batched decode against the CPU ORACLE (not against the single-sequence HIP path): every sequence of a 5-prompt batch

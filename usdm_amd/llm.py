@@ -695,6 +695,13 @@ class USDMForCausalLM:
 
     MAX_BATCH = 16      # sequences per decode step (usdm_gemv_batch: VALU form up to 4, matrix-core form up to 16)
 
+    def max_batch(self):
+        """Sequences one decode step can take with THIS model's (per-rank) shapes: 16 on the matrix-core form, which splits K over
+        8 waves in chunks of 32 (every projection's K must be a multiple of 256), else the 4 of the VALU form."""
+        c = self.cfg
+        ks = (c["hidden_size"], self.Hq * c["head_dim"], self.I)
+        return self.MAX_BATCH if all(k % 256 == 0 for k in ks) else 4
+
     @torch.no_grad()
     def generate_batch(self, input_ids_list, max_new_tokens, bad_words_ids=None, eos_token_id=None, min_new_tokens=0, group=None):
         """Greedy generation of several utterances in lockstep (the serving-side batching of inference_vllm.py:109-125): up to
@@ -702,7 +709,7 @@ class USDMForCausalLM:
         step then streams the weights once for the whole group.  Groups of <= 4 run on the VALU kernel and equal generate() per
         sequence bit for bit; larger groups run on the matrix cores (usdm_gemv_batch form 1): the same rounding points, K summed
         in another order - equal to the oracle up to its near-ties, not bit-identical with generate()."""
-        group = self.MAX_BATCH if group is None else max(1, min(int(group), self.MAX_BATCH))
+        group = self.max_batch() if group is None else max(1, min(int(group), self.max_batch()))
         outs = []
         for g0 in range(0, len(input_ids_list), group):
             outs += self._generate_group(input_ids_list[g0:g0 + group], max_new_tokens, bad_words_ids, eos_token_id, min_new_tokens)

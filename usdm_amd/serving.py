@@ -233,7 +233,7 @@ class LLM:
     def _run_batched(self, grp):
         llm = self.llm
         from . import ops
-        nslots = min(self.max_slots, SMALL_SLOTS if len(grp) <= SMALL_SLOTS else MAX_SLOTS)
+        nslots = min(self.max_slots, llm.max_batch(), SMALL_SLOTS if len(grp) <= SMALL_SLOTS else MAX_SLOTS)
         bb = llm._batch_buffers(nslots)
         sampled = any(not r["sp"].greedy for r in grp)       # one sampled request -> the whole group runs on the sampling graph
         key = "decode_sampled" if sampled else "decode"
