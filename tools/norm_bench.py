@@ -22,3 +22,21 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (5 * 48)
 print(f"norm [2236][1024]: {us:.2f} us  ({R * C * 10 / us / 1e6:.2f} TB/s over 10 B/element)")
+# the 7B's RMSNorm in a prefill: [S][4096] bf16 -> bf16 (HF rounding points), S = 38 and 548
+for S in (38, 548):
+    C = 4096
+    hs = [torch.randn(S, C, device=dev).bfloat16() for _ in range(8)]
+    gw = torch.randn(C, device=dev)
+    xn = torch.zeros(S, C, device=dev, dtype=torch.bfloat16)
+    plan = ops.Plan()
+    for i in range(48):
+        ops.norm(hs[i % 8], gw, None, rows=S, C=C, eps=1e-5, rms=True, round_bf16=True, out16=xn, plan=plan)
+    gp = GraphedPlan(plan)
+    for _ in range(3):
+        gp.run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        gp.run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"rmsnorm [{S}][4096] bf16: {e0.elapsed_time(e1) * 1e3 / (5 * 48):.2f} us")

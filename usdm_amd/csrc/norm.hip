@@ -25,17 +25,21 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
   const int npieces = a.C >> 2;
   float4 v[NP];
   // gamma / beta do not depend on the row statistics: requested together with the row so that the kernel pays one memory
-  // latency, not two (NP <= 5 only: the wide instantiations would spill)
-  constexpr bool PRE = NP <= 5;
-  float4 gpre[PRE ? NP : 1], bpre[PRE ? NP : 1];
+  // latency, not two.  beta: NP <= 5 only (the wide instantiations would spill); gamma: up to NP = 16 (round 4: the 7B's RMSNorm
+  // rows of 4096 loaded gamma piece by piece behind the statistics - 16 dependent L2 latencies, 15 - 17 us per launch of a prefill)
+  constexpr bool PRE = NP <= 16, PREB = NP <= 5;
+  float4 gpre[PRE ? NP : 1], bpre[PREB ? NP : 1];
   if constexpr (PRE) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int idx = p * 64 + lane;
-      gpre[p] = make_float4(0.f, 0.f, 0.f, 0.f); bpre[p] = gpre[p];
+      gpre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (PREB) bpre[p] = gpre[p];
       if (idx < npieces) {
         gpre[p] = *(const float4*)(a.gamma + idx * 4);
-        if (a.beta) bpre[p] = *(const float4*)(a.beta + idx * 4);
+        if constexpr (PREB) {
+          if (a.beta) bpre[p] = *(const float4*)(a.beta + idx * 4);
+        }
       }
     }
   }
@@ -44,40 +48,100 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
     const int b = row / a.rows_per_batch, s = row - b * a.rows_per_batch;
     zero_row = s >= a.valid_len[b];
   }
+  // Loads first, arithmetic second (round 4): with the dtype / residual / addend tests inside the per-piece loop every piece paid its
+  // own memory latencies one after the other (the wait-count pass drains at each join) - 14 us for a 38 x 4096 RMSNorm, 16 L2
+  // latencies.  Each source is now requested for ALL pieces back to back; the per-element order of the additions is unchanged
+  // (x, + res, rounding, + res2[0], + res2[1] ...), so results are bit-identical.
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.x_dtype == USDM_F32) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int idx = p * 64 + lane;
+      v[p] = idx < npieces ? *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + idx * 4) : zero4;
+    }
+  } else {
+    uint2 r[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int idx = p * 64 + lane;
+      r[p] = idx < npieces ? *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + idx * 4) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = make_float4(bf2f(r[p].x & 0xffff), bf2f(r[p].x >> 16), bf2f(r[p].y & 0xffff), bf2f(r[p].y >> 16));
+  }
+  if (a.res) {
+    if (a.res_dtype == USDM_F32) {
+      if constexpr (NP <= 5) {
+        float4 r4[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int idx = p * 64 + lane;
+          r4[p] = idx < npieces ? *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4) : zero4;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { v[p].x += r4[p].x; v[p].y += r4[p].y; v[p].z += r4[p].z; v[p].w += r4[p].w; }
+      } else {      // wide rows: piece by piece (a second full set of f32 registers would spill)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int idx = p * 64 + lane;
+          if (idx < npieces) {
+            const float4 r4 = *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4);
+            v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+          }
+        }
+      }
+    } else {
+      uint2 r[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int idx = p * 64 + lane;
+        r[p] = idx < npieces ? *(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + idx * 4) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        v[p].x += bf2f(r[p].x & 0xffff); v[p].y += bf2f(r[p].x >> 16); v[p].z += bf2f(r[p].y & 0xffff); v[p].w += bf2f(r[p].y >> 16);
+      }
+    }
+    if (a.round_bf16) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { v[p].x = round_bf(v[p].x); v[p].y = round_bf(v[p].y); v[p].z = round_bf(v[p].z); v[p].w = round_bf(v[p].w); }
+    }
+  }
+  for (int e2 = 0; e2 < a.n_res2; ++e2) {              // further f32 addends (split-K partials of the producing GEMM), in order
+    const float* rp = a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr;
+    if constexpr (NP <= 5) {
+      float4 r4[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int idx = p * 64 + lane;
+        r4[p] = idx < npieces ? *(const float4*)(rp + idx * 4) : zero4;
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { v[p].x += r4[p].x; v[p].y += r4[p].y; v[p].z += r4[p].z; v[p].w += r4[p].w; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int idx = p * 64 + lane;
+        if (idx < npieces) {
+          const float4 r4 = *(const float4*)(rp + idx * 4);
+          v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int idx = p * 64 + lane;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < npieces) {
-      if (a.x_dtype == USDM_F32) {
-        x = *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + idx * 4);
-      } else {
-        const uint2 r = *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + idx * 4);
-        x = make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
-      }
-      if (a.res) {
-        float4 r4;
-        if (a.res_dtype == USDM_F32) {
-          r4 = *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4);
-        } else {
-          const uint2 r = *(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + idx * 4);
-          r4 = make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
-        }
-        x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
-        if (a.round_bf16) { x.x = round_bf(x.x); x.y = round_bf(x.y); x.z = round_bf(x.z); x.w = round_bf(x.w); }
-      }
-      for (int e2 = 0; e2 < a.n_res2; ++e2) {              // further f32 addends (split-K partials of the producing GEMM), in order
-        const float4 r4 = *(const float4*)(a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr + idx * 4);
-        x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
-      }
-      if (a.premask && zero_row) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.sum32) NST((float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4), x);
+      if (a.premask && zero_row) v[p] = zero4;
+      if (a.sum32) NST((float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4), v[p]);
       if (a.sum16) {
-        uint2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
+        uint2 o; o.x = pack_bf2(v[p].x, v[p].y); o.y = pack_bf2(v[p].z, v[p].w);
         NST((uint2*)((bf16_t*)a.sum16 + (int64_t)row * a.lds + idx * 4), o);
       }
+    } else {
+      v[p] = zero4;
     }
-    v[p] = x;
   }
   float s = 0.f;
 #pragma unroll
@@ -102,7 +166,9 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
     if (idx >= npieces) continue;
     float4 gm, bt = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PRE) {
-      gm = gpre[p]; bt = bpre[p];
+      gm = gpre[p];
+      if constexpr (PREB) bt = bpre[p];
+      else if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
     } else {
       gm = *(const float4*)(a.gamma + idx * 4);
       if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
