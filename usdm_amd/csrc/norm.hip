@@ -32,93 +32,130 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
   if constexpr (PRE) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int idx = p * 64 + lane;
-      gpre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (PREB) bpre[p] = gpre[p];
-      if (idx < npieces) {
-        gpre[p] = *(const float4*)(a.gamma + idx * 4);
-        if constexpr (PREB) {
-          if (a.beta) bpre[p] = *(const float4*)(a.beta + idx * 4);
-        }
+      const int idc = min(p * 64 + lane, npieces - 1) * 4;      // (unconditional: pieces past the row are never used)
+      gpre[p] = *(const float4*)(a.gamma + idc);
+    }
+    if constexpr (PREB) {
+      if (a.beta) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bpre[p] = *(const float4*)(a.beta + min(p * 64 + lane, npieces - 1) * 4);
       }
     }
   }
-  bool zero_row = false;
-  if (a.valid_len) {
-    const int b = row / a.rows_per_batch, s = row - b * a.rows_per_batch;
-    zero_row = s >= a.valid_len[b];
-  }
   // Loads first, arithmetic second (round 4): with the dtype / residual / addend tests inside the per-piece loop every piece paid its
-  // own memory latencies one after the other (the wait-count pass drains at each join) - 14 us for a 38 x 4096 RMSNorm, 16 L2
-  // latencies.  Each source is now requested for ALL pieces back to back; the per-element order of the additions is unchanged
-  // (x, + res, rounding, + res2[0], + res2[1] ...), so results are bit-identical.
+  // own memory latencies one after the other (the wait-count pass drains at each join) - 14 us for a 38 x 4096 RMSNorm.  The
+  // per-element order of the additions is unchanged (x, + res, rounding, + res2[0], + res2[1] ...), so results are bit-identical.
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.x_dtype == USDM_F32) {
+  const uint2 zero2 = make_uint2(0u, 0u);
+  auto cvt = [](uint2 r) { return make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16)); };
+  if constexpr (NP <= 5) {
+    // narrow rows (Voicebox, XLS-R): EVERY source - x, the residual, up to three split-K addends - is requested before the first
+    // addition, whatever the dtypes (the branches below hold loads only: nothing waits at their joins)
+    constexpr int ME = 3;
+    float4 x4[NP], q4[NP], e4[ME][NP];
+    uint2 x2[NP], q2[NP];
+    const bool xf = a.x_dtype == USDM_F32, rf = a.res_dtype == USDM_F32;
+    const int ne = a.n_res2 < ME ? a.n_res2 : ME;
+    // per-lane validity is applied AFTER the loads (pieces past the row re-read its last piece): a predicated load would have
+    // to be merged with its zero at the join, i.e. waited for on the spot
+    int ic[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int idx = p * 64 + lane;
-      v[p] = idx < npieces ? *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + idx * 4) : zero4;
+    for (int p = 0; p < NP; ++p) ic[p] = min(p * 64 + lane, npieces - 1) * 4;
+    // (x4 / x2, q4 / q2, e4: only the set that was loaded is read below - the other stays unwritten ON PURPOSE: initialising it would
+    // put a merge of {zero, loaded} at the join of the branch, and the wait-count pass makes the wave wait for the load there)
+    if (xf) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) x4[p] = *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + ic[p]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) x2[p] = *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + ic[p]);
+    }
+    if (a.res) {
+      if (rf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) q4[p] = *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + ic[p]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) q2[p] = *(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + ic[p]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < ME; ++e) {
+      if (e < ne) {
+        const float* rp = a.res2 + (int64_t)e * a.res2_stride + (int64_t)row * a.ldr;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) e4[e][p] = *(const float4*)(rp + ic[p]);
+      }
+    }
+    // ---- arithmetic, in the order the piece-by-piece form used: x, + res, rounding, + addend 0, + addend 1 ...
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = (p * 64 + lane < npieces) ? (xf ? x4[p] : cvt(x2[p])) : zero4;
+    if (a.res) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float4 r4 = (p * 64 + lane < npieces) ? (rf ? q4[p] : cvt(q2[p])) : zero4;
+        v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+      }
+      if (a.round_bf16) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { v[p].x = round_bf(v[p].x); v[p].y = round_bf(v[p].y); v[p].z = round_bf(v[p].z); v[p].w = round_bf(v[p].w); }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < ME; ++e) {
+      if (e < ne) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float4 r4 = (p * 64 + lane < npieces) ? e4[e][p] : zero4;
+          v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+        }
+      }
+    }
+    for (int e2 = ME; e2 < a.n_res2; ++e2) {
+      const float* rp = a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (p * 64 + lane < npieces) {
+          const float4 r4 = *(const float4*)(rp + (p * 64 + lane) * 4);
+          v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+        }
+      }
     }
   } else {
-    uint2 r[NP];
+    // wide rows (the 7B's 4096): x for all pieces first; residual / addends piece by piece (a second full register set would spill)
+    if (a.x_dtype == USDM_F32) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int idx = p * 64 + lane;
-      r[p] = idx < npieces ? *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + idx * 4) : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) v[p] = make_float4(bf2f(r[p].x & 0xffff), bf2f(r[p].x >> 16), bf2f(r[p].y & 0xffff), bf2f(r[p].y >> 16));
-  }
-  if (a.res) {
-    if (a.res_dtype == USDM_F32) {
-      if constexpr (NP <= 5) {
-        float4 r4[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int idx = p * 64 + lane;
-          r4[p] = idx < npieces ? *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4) : zero4;
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { v[p].x += r4[p].x; v[p].y += r4[p].y; v[p].z += r4[p].z; v[p].w += r4[p].w; }
-      } else {      // wide rows: piece by piece (a second full set of f32 registers would spill)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int idx = p * 64 + lane;
-          if (idx < npieces) {
-            const float4 r4 = *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4);
-            v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
-          }
-        }
+      for (int p = 0; p < NP; ++p) {
+        const int idx = p * 64 + lane;
+        v[p] = idx < npieces ? *(const float4*)((const float*)a.x + (int64_t)row * a.ldx + idx * 4) : zero4;
       }
     } else {
       uint2 r[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int idx = p * 64 + lane;
-        r[p] = idx < npieces ? *(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + idx * 4) : make_uint2(0u, 0u);
+        r[p] = idx < npieces ? *(const uint2*)((const bf16_t*)a.x + (int64_t)row * a.ldx + idx * 4) : zero2;
       }
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        v[p].x += bf2f(r[p].x & 0xffff); v[p].y += bf2f(r[p].x >> 16); v[p].z += bf2f(r[p].y & 0xffff); v[p].w += bf2f(r[p].y >> 16);
-      }
+      for (int p = 0; p < NP; ++p) v[p] = cvt(r[p]);
     }
-    if (a.round_bf16) {
-#pragma unroll
-      for (int p = 0; p < NP; ++p) { v[p].x = round_bf(v[p].x); v[p].y = round_bf(v[p].y); v[p].z = round_bf(v[p].z); v[p].w = round_bf(v[p].w); }
-    }
-  }
-  for (int e2 = 0; e2 < a.n_res2; ++e2) {              // further f32 addends (split-K partials of the producing GEMM), in order
-    const float* rp = a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr;
-    if constexpr (NP <= 5) {
-      float4 r4[NP];
+    if (a.res) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int idx = p * 64 + lane;
-        r4[p] = idx < npieces ? *(const float4*)(rp + idx * 4) : zero4;
+        if (idx < npieces) {
+          const float4 r4 = a.res_dtype == USDM_F32 ? *(const float4*)((const float*)a.res + (int64_t)row * a.ldr + idx * 4)
+                                                    : cvt(*(const uint2*)((const bf16_t*)a.res + (int64_t)row * a.ldr + idx * 4));
+          v[p].x += r4.x; v[p].y += r4.y; v[p].z += r4.z; v[p].w += r4.w;
+        }
       }
+      if (a.round_bf16) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) { v[p].x += r4[p].x; v[p].y += r4[p].y; v[p].z += r4[p].z; v[p].w += r4[p].w; }
-    } else {
+        for (int p = 0; p < NP; ++p) { v[p].x = round_bf(v[p].x); v[p].y = round_bf(v[p].y); v[p].z = round_bf(v[p].z); v[p].w = round_bf(v[p].w); }
+      }
+    }
+    for (int e2 = 0; e2 < a.n_res2; ++e2) {
+      const float* rp = a.res2 + (int64_t)e2 * a.res2_stride + (int64_t)row * a.ldr;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int idx = p * 64 + lane;
@@ -129,11 +166,18 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
       }
     }
   }
+  // (the padding-row test is made where it is first needed: AFTER the row's loads were issued: at the join of this branch the wait-count pass waits for everything requested so far)
+  int vlen = 0x7fffffff, srow = 0;
+  if (a.valid_len) {
+    const int b = row / a.rows_per_batch;
+    srow = row - b * a.rows_per_batch;
+    vlen = a.valid_len[b];
+  }
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int idx = p * 64 + lane;
     if (idx < npieces) {
-      if (a.premask && zero_row) v[p] = zero4;
+      if (a.premask && srow >= vlen) v[p] = zero4;
       if (a.sum32) NST((float4*)((float*)a.sum32 + (int64_t)row * a.lds + idx * 4), v[p]);
       if (a.sum16) {
         uint2 o; o.x = pack_bf2(v[p].x, v[p].y); o.y = pack_bf2(v[p].z, v[p].w);
@@ -167,7 +211,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
     float4 gm, bt = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PRE) {
       gm = gpre[p];
-      if constexpr (PREB) bt = bpre[p];
+      if constexpr (PREB) { if (a.beta) bt = bpre[p]; }
       else if (a.beta) bt = *(const float4*)(a.beta + idx * 4);
     } else {
       gm = *(const float4*)(a.gamma + idx * 4);
@@ -181,7 +225,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const usdm_norm_args a) {
       if (a.round_bf16) t = round_bf(round_bf(t) * g4[e]);  // HF: weight * hidden.to(bf16)
       else t = t * g4[e] + b4[e];
       if (a.act == USDM_ACT_GELU) t = gelu_erf(t);
-      if (zero_row) t = 0.f;
+      if (srow >= vlen) t = 0.f;
       y[e] = t;
     }
     if (a.out32) NST((float4*)((float*)a.out32 + (int64_t)row * a.ldo + idx * 4), make_float4(y[0], y[1], y[2], y[3]));
