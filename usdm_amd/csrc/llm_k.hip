@@ -14,6 +14,9 @@
 #ifndef USDM_UNR1
 #define USDM_UNR1 8   // ring depth of the one-row-per-wave variants (o_proj / down_proj)
 #endif
+#ifndef USDM_GEMV_RES_PREFETCH
+#define USDM_GEMV_RES_PREFETCH 1   // 0: the residual is read in the epilogue (A/B builds)
+#endif
 namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
@@ -117,6 +120,15 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
 #pragma unroll
     for (int j = 0; j < NR; ++j)
       if (u < nit) ring[j][u] = wload(j, u);
+  // The residual values of this wave's rows are requested HERE, behind the first ring, not in the epilogue (round 4): there the
+  // load was a full memory latency at the very end of every o_proj / down_proj launch, with nothing left to hide it.  Unconditional
+  // (a predicated load is waited for at the join of its predicate): without a residual the address is the weight row, never used.
+  unsigned short resraw[GLU ? 1 : NR];
+  if constexpr (!GLU && USDM_GEMV_RES_PREFETCH) {
+    const bf16_t* rbase = a.residual ? (const bf16_t*)a.residual : (const bf16_t*)a.W;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) resraw[j] = rbase[min(ob + j, a.N - 1)];
+  }
 
   GTR(1);
   if (skipv) return;   // the sequence ended in an earlier step of this host chunk (usdm_decode_state.done)
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
       float v = acc[j];
       if (a.round_bf16) v = round_bf(v);
       if (a.residual) {
-        v += bf2f(((const bf16_t*)a.residual)[n]);
+        v += USDM_GEMV_RES_PREFETCH ? bf2f(resraw[j]) : bf2f(((const bf16_t*)a.residual)[n]);
         if (a.round_bf16) v = round_bf(v);
       }
       if (a.y16) ((bf16_t*)a.y16)[n] = f2bf(v);
