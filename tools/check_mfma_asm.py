@@ -43,6 +43,13 @@ for pat in pats:
                 used |= regs(tok)
             if any(used & f for f in fifo):
                 bad.append((i - i0, code.strip()))
+            # compiler-issued vector memory operations and waits move the same in-order counter (kernels that mix both kinds)
+            if re.search(r"\b(global|buffer|scratch|flat)_(load|store|atomic)", code):
+                fifo.append(set())
+            m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", code)
+            if m:
+                n = int(m.group(1))
+                fifo = fifo[len(fifo) - n:] if n else []
     print(f"{pat}: {nload} asm loads; compiler instructions that touch a register while its asm load is in flight: {len(bad)}")
     for b in bad[:20]:
         print("  ", b)

@@ -14,6 +14,9 @@
 #ifndef USDM_UNR1
 #define USDM_UNR1 8   // ring depth of the one-row-per-wave variants (o_proj / down_proj)
 #endif
+#ifndef USDM_GEMV_X_FIRST
+#define USDM_GEMV_X_FIRST 1   // 0: the input vector is requested behind the first weight ring and read twice by the RMSNorm prologue (A/B builds)
+#endif
 #ifndef USDM_GEMV_RES_PREFETCH
 #define USDM_GEMV_RES_PREFETCH 1   // 0: the residual is read in the epilogue (A/B builds)
 #endif
@@ -114,13 +117,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     const u32x4* p = (it == nit - 1 && !tail_ok) ? wp[j] - lane : wp[j] + it * 64;
     return __builtin_nontemporal_load(p);
   };
-  u32x4 ring[NR][UNR];
-#pragma unroll
-  for (int u = 0; u < UNR; ++u)
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-      if (u < nit) ring[j][u] = wload(j, u);
-  // The residual values of this wave's rows are requested HERE, behind the first ring, not in the epilogue (round 4): there the
+  // The residual values of this wave's rows are requested HERE, at the start, not in the epilogue (round 4): there the
   // load was a full memory latency at the very end of every o_proj / down_proj launch, with nothing left to hide it.  Unconditional
   // (a predicated load is waited for at the join of its predicate): without a residual the address is the weight row, never used.
   unsigned short resraw[GLU ? 1 : NR];
@@ -129,15 +126,50 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
 #pragma unroll
     for (int j = 0; j < NR; ++j) resraw[j] = rbase[min(ob + j, a.N - 1)];
   }
-
+  // (round 4) This thread's first piece of the input vector and its RMSNorm weights are requested BEFORE the weight ring.  Loads
+  // return in order: behind the ring they landed only when the whole ring had (~2 us), and the RMSNorm prologue - sum of squares,
+  // barrier, a SECOND read of x and of the weights, normalise, barrier - started after that, with no weight load of this workgroup
+  // in flight.  Now the prologue runs under the ring's latency and reads nothing twice.  Unconditional loads (clamped index; a
+  // dummy address without RMSNorm): a predicated load would be waited for at the join of its predicate, i.e. before the ring is
+  // issued.  Not in the merged-input variants (their x is not in memory).
+  constexpr bool EARLY = USDM_GEMV_X_FIRST && !CMB && !MRG;
+  const int i0 = tid * 8;
+  // The three loads are HAND-COUNTED (asm, invisible to the compiler; cdna_hip_programming.md 5.7): the ring below is issued under
+  // run-time tests (u < nit), so the wait-count pass cannot know how many loads are younger than x0 and would wait for all but the
+  // few it is sure of - the whole ring again.  The wait further down names the exact count for the full-ring case.
+  u32x4 x0 = {0u, 0u, 0u, 0u}, ge0v = x0, ge1v = x0;
+  if constexpr (EARLY) {
+    const int ic = min(i0, K - 8);
+    const float* gp = a.norm_w ? a.norm_w : (const float*)a.W;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x0) : "v"((const bf16_t*)a.x + ic) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge0v) : "v"(gp + ic) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge1v) : "v"(gp + ic + 4) : "memory");
+  }
+  // The first ring is ALWAYS NR x UNR loads (slots past the row's K, or of a wave whose rows are all banned, re-read the row start
+  // and are never multiplied / their results never used): the wait for the early loads below can then name an exact count.
+  u32x4 ring[NR][UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const bool real = active && u < nit;
+      const u32x4* p = real ? ((u == nit - 1 && !tail_ok) ? wp[j] - lane : wp[j] + u * 64) : wp[j] - lane;
+      ring[j][u] = __builtin_nontemporal_load(p);
+    }
   GTR(1);
+  if constexpr (EARLY) {
+    // in-order completion: "all but the NY youngest" = the three early loads have landed, the ring stays in flight.  ONE wait site on
+    // every path (two sites in two branches made the compiler copy the registers of the loads at the branch - before the wait)
+    constexpr int NY = UNR * NR;      // (the residual loads above are older: nothing else is issued between the early loads and here)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x0), "+v"(ge0v), "+v"(ge1v) : "n"(NY));
+  }
   if (skipv) return;   // the sequence ended in an earlier step of this host chunk (usdm_decode_state.done)
+  const float4 ge0 = __builtin_bit_cast(float4, ge0v), ge1 = __builtin_bit_cast(float4, ge1v);
   // ---- stage x into LDS (optionally fused RMSNorm with HF rounding) while the first ring is in flight
   const bf16_t* xg = (const bf16_t*)a.x;
   // 8 consecutive elements of the input vector; with x_delta the pending residual add of the tensor-parallel path is applied
   // on the fly (HF rounding: bf16(h + bf16(delta))) and workgroup 0 publishes the updated residual stream
-  auto ldx = [&](int i, bool publish) -> u32x4 {
-    u32x4 v = *(const u32x4*)(xg + i);
+  auto with_delta = [&](u32x4 v, int i, bool publish) -> u32x4 {
     if (a.x_delta) {
       const float4 d0 = *(const float4*)(a.x_delta + i), d1 = *(const float4*)(a.x_delta + i + 4);
       const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -148,9 +180,22 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
     }
     return v;
   };
+  auto ldx = [&](int i, bool publish) -> u32x4 { return with_delta(*(const u32x4*)(xg + i), i, publish); };
+  const int iloop = EARLY ? i0 + NTH * 8 : i0;               // EARLY: the first piece is x0, the loops below take the rest
   if (a.norm_w) {
     float ss = 0.f;
-    for (int i = tid * 8; i < K; i += NTH * 8) {
+    u32x4 v0 = x0;
+    if constexpr (EARLY) {
+      if (i0 < K) {
+        v0 = with_delta(x0, i0, false);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf2f(v0[e] & 0xffff), hi = bf2f(v0[e] >> 16);
+          ss += lo * lo + hi * hi;
+        }
+      }
+    }
+    for (int i = iloop; i < K; i += NTH * 8) {
       const u32x4 v = ldx(i, false);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -165,7 +210,22 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
 #pragma unroll
     for (int w = 0; w < NWV; ++w) tot += red[w];
     const float rstd = rsqrtf(tot / (float)K + a.eps);
-    for (int i = tid * 8; i < Kpad; i += NTH * 8) {
+    if constexpr (EARLY) {
+      if (i0 < Kpad) {
+        u32x4 o = {0, 0, 0, 0};
+        if (i0 < K) {
+          if (a.x_delta && a.x_out && blockIdx.x == 0) *(u32x4*)((bf16_t*)a.x_out + i0) = v0;
+          const float gw[8] = {ge0.x, ge0.y, ge0.z, ge0.w, ge1.x, ge1.y, ge1.z, ge1.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = bf2f(v0[e] & 0xffff), hi = bf2f(v0[e] >> 16);
+            o[e] = pack_bf2(round_bf(round_bf(lo * rstd) * gw[2 * e]), round_bf(round_bf(hi * rstd) * gw[2 * e + 1]));
+          }
+        }
+        *(u32x4*)(xs + i0) = o;
+      }
+    }
+    for (int i = iloop; i < Kpad; i += NTH * 8) {
       u32x4 o = {0, 0, 0, 0};
       if (i < K) {
         const u32x4 v = ldx(i, true);
@@ -268,7 +328,14 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
       *(u32x2*)(xs + i) = r;
     }
   } else {
-    for (int i = tid * 8; i < Kpad; i += NTH * 8) {
+    if constexpr (EARLY) {
+      if (i0 < Kpad) {
+        u32x4 v = {0, 0, 0, 0};
+        if (i0 < K) v = with_delta(x0, i0, true);
+        *(u32x4*)(xs + i0) = v;
+      }
+    }
+    for (int i = iloop; i < Kpad; i += NTH * 8) {
       u32x4 v = {0, 0, 0, 0};
       if (i < K) v = ldx(i, true);
       *(u32x4*)(xs + i) = v;
