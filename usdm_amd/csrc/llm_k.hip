@@ -140,10 +140,12 @@ __global__ __launch_bounds__(NWV * 64) void gemv_kernel(const usdm_gemv_args a) 
   u32x4 x0 = {0u, 0u, 0u, 0u}, ge0v = x0, ge1v = x0;
   if constexpr (EARLY) {
     const int ic = min(i0, K - 8);
-    const float* gp = a.norm_w ? a.norm_w : (const float*)a.W;
+    // (without RMSNorm the two weight loads re-read the first 16 bytes of x - always there, K >= 8 - and are not used)
+    const float* gp0 = a.norm_w ? a.norm_w + ic : (const float*)a.x;
+    const float* gp1 = a.norm_w ? gp0 + 4 : gp0;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x0) : "v"((const bf16_t*)a.x + ic) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge0v) : "v"(gp + ic) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge1v) : "v"(gp + ic + 4) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge0v) : "v"(gp0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ge1v) : "v"(gp1) : "memory");
   }
   // The first ring is ALWAYS NR x UNR loads (slots past the row's K, or of a wave whose rows are all banned, re-read the row start
   // and are never multiplied / their results never used): the wait for the early loads below can then name an exact count.
